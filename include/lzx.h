@@ -1,0 +1,161 @@
+/*
+ * lzx.h -- C ABI of the MI355X-native Lanczos e^A x engine (liblzx.so).
+ *
+ * This is the drop-in boundary for the hot path of hdelan/MSc-HPC-Final-Project
+ * (SURVEY.md section 8): everything `lanczosDecomp<T>::cu_decompose()` does on the
+ * device in parallel-final, behind plain pointers and sizes.  The reference has no
+ * FFI of its own (one C++ binary); each entry point below names the reference
+ * code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns LZX_OK (0) or a negative lzx_status; the message of
+ *     the last failure on the calling thread is lzx_last_error();
+ *   - all pointers are HOST pointers owned by the caller unless a name ends in
+ *     `_dev`; the library owns all device memory;
+ *   - a handle is bound to one GPU and is not thread-safe; distinct handles are;
+ *   - the graph is an undirected, unweighted adjacency matrix handed over as
+ *     pattern-only CSR (no values array): symmetric, columns ascending within a
+ *     row, no duplicates -- what adjMatrix holds (parallel-final/lib/adjMatrix.h:26-30);
+ *   - vertex order at this boundary is always the caller's; the library is free
+ *     to (and does) relabel internally.
+ */
+#ifndef LZX_H_
+#define LZX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lzx_ctx *lzx_handle;
+
+typedef enum lzx_status {
+    LZX_OK = 0,
+    LZX_ERR_ARG = -1,    /* bad argument (null pointer, k == 0, sizes that do not match) */
+    LZX_ERR_HIP = -2,    /* a HIP runtime call or kernel launch failed                   */
+    LZX_ERR_STATE = -3,  /* call order: no graph yet, no decomposition yet, ...          */
+    LZX_ERR_NOMEM = -4,  /* host or device allocation failed                             */
+    LZX_ERR_COMM = -5,   /* RCCL not loadable / communicator failure                     */
+    LZX_ERR_LIMIT = -6   /* size outside what this build supports (nnz per rank >= 2^32) */
+} lzx_status;
+
+/* Timings of the last lzx_lanczos_f64 call (all in milliseconds). */
+typedef struct lzx_stats {
+    double loop_ms;       /* host wall clock around the k-iteration loop, device-synchronised on both
+                             sides; excludes upload of x0 and download of alpha/beta/Q              */
+    double spmv_ms;       /* sum over iterations of the SpMV(+alpha partial) launches, HIP events on
+                             the stream they run on                                                */
+    double spmv_ms_min;   /* fastest single iteration's SpMV time                                   */
+    double vec_ms;        /* sum of the axpy+norm and scale launches                                */
+    double comm_ms;       /* sum of the exchange steps (all-reduce x2 + all-gather), 0 at one rank  */
+    uint32_t iters;       /* k                                                                      */
+    uint32_t spmv_kernels;/* kernel launches counted in spmv_ms per iteration                       */
+    uint64_t spmv_bytes;  /* algorithmic bytes of ONE SpMV on this rank:
+                             4*nnz_local + 4*(rows_local+1) + 8*n (x once) + 8*rows_local (y)       */
+} lzx_stats;
+
+typedef struct lzx_graph_info {
+    uint64_t n;           /* vertices (global)                                   */
+    uint64_t nnz;         /* stored entries of the whole matrix = 2 * undirected edges */
+    uint64_t max_degree;
+    uint64_t rows_local;  /* rows this rank owns                                 */
+    uint64_t nnz_local;   /* entries in those rows                               */
+    uint64_t long_rows;   /* local rows handled by the split-row path            */
+    uint64_t sell_padded; /* entries of the sliced-ELL body including padding    */
+    uint32_t hub_entries; /* x entries staged in LDS per workgroup               */
+    uint32_t world, rank;
+} lzx_graph_info;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* Create an engine on GPU `device_id`.  Replaces the cudaMalloc/cudaStreamCreate block of
+ * cu_decompose (parallel-final/lib/cu_lanczos.cu:37-86); unlike it, failure leaves nothing
+ * half-built.                                                                                    */
+int lzx_create(lzx_handle *out, int device_id);
+void lzx_destroy(lzx_handle h);
+const char *lzx_last_error(void);
+
+/* ---- multi-GPU wiring (optional; call before handing over the graph) ----------------------------
+ * Rows are dealt to ranks by degree rank (round-robin), every rank keeps a full-length copy of the
+ * current Lanczos vector, and each iteration ends with an all-gather of the owned slices plus two
+ * one-double all-reduces.  Replaces parallel-two-cards' split at rows0 = n/2 and its two
+ * cudaMemcpyPeer per iteration (parallel-two-cards/lib/cu_lanczos.cu:62-67,125,158).
+ *   lzx_comm_unique_id / lzx_comm_init_rank : one process per GPU, RCCL over xGMI.  Rank 0 makes the
+ *       128-byte id, the caller ships it to the other ranks (any side channel), everyone calls init.
+ *   lzx_comm_init_local : `world` handles inside ONE process (the reference's own two-cards model,
+ *       any number of cards); exchanges are device-to-device copies.  Handles may share a GPU.      */
+int lzx_comm_unique_id(uint8_t id[128]);
+int lzx_comm_init_rank(lzx_handle h, const uint8_t id[128], int rank, int world);
+int lzx_comm_init_local(lzx_handle *hs, int world);
+
+/* ---- graph hand-over ---------------------------------------------------------------------------
+ * lzx_set_graph_csr: upload of IA/JA, parallel-final/lib/cu_lanczos.cu:88-94 (`row_offset[n+1]`,
+ * `col_idx[2E]`).  row_ptr is 64-bit as in serial/ (serial/lib/adjMatrix.h:23-24);
+ * lzx_set_graph_csr32 takes parallel-final's `unsigned` arrays as they are.  Every rank of a
+ * communicator passes the same whole graph and keeps its share.                                  */
+int lzx_set_graph_csr(lzx_handle h, uint64_t n, uint64_t nnz, const uint64_t *row_ptr,
+                      const uint32_t *col_idx);
+int lzx_set_graph_csr32(lzx_handle h, uint32_t n, uint32_t nnz, const uint32_t *row_ptr,
+                        const uint32_t *col_idx);
+
+/* Device-side ingest: `m` undirected edges as 0-based endpoint pairs, in any
+ * order, duplicates and self loops allowed; symmetrised, sorted and de-duplicated on the GPU into
+ * the CSR that adjMatrix::populate_sparse_matrix builds with a std::set
+ * (parallel-final/lib/adjMatrix.cc:21-46).                                                        */
+int lzx_set_graph_edges(lzx_handle h, uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst);
+
+/* Seeded synthetic graphs generated on the GPU (the reference's generators are seeded from
+ * std::random_device, parallel-final/lib/make_graph.cc:23-24,61-62, and cannot be reproduced).
+ * Integer specification shared with oracle/lanczos_oracle.c (orc_gen_er_keys, orc_gen_rmat_keys).
+ * kind 0: Erdos-Renyi G(n, draws); kind 1: R-MAT with `scale` levels, 16-bit thresholds ta/tab/tabc,
+ * endpoints >= n re-drawn (up to 8 attempts).                                                      */
+int lzx_gen_graph(lzx_handle h, int kind, uint32_t scale, uint64_t n, uint64_t draws, uint64_t seed,
+                  uint32_t ta, uint32_t tab, uint32_t tabc);
+
+int lzx_get_graph_info(lzx_handle h, lzx_graph_info *out);
+/* Copy the whole-graph CSR (caller's vertex order) back to the host: row_ptr[n+1], col_idx[nnz]. */
+int lzx_get_graph_csr(lzx_handle h, uint64_t *row_ptr, uint32_t *col_idx);
+
+/* ---- hot path ----------------------------------------------------------------------------------
+ * lzx_spmv_f64: y = A x.  Kernel-level parity hook for cu_spMV1 (parallel-final/lib/cu_SPMV.cu:31-41)
+ * and CPU spMV (serial/lib/SPMV.cc:19-28).  x[n], y[n] in the caller's vertex order.              */
+int lzx_spmv_f64(lzx_handle h, const double *x, double *y);
+int lzx_spmv_f64_local(lzx_handle *hs, int world, const double *x, double *y);
+
+/* lzx_lanczos_f64: the whole k-step loop of cu_decompose (parallel-final/lib/cu_lanczos.cu:97-130),
+ * i.e. serial/lib/lanczos.cc:9-56 on the device:
+ *     q_0 = x0/||x0||;  for j<k: v = A q_j; alpha_j = v.q_j; v -= alpha_j q_j; v -= beta_{j-1} q_{j-1};
+ *                                 beta_j = ||v||; q_{j+1} = v/beta_j          (last two only for j<k-1)
+ * Outputs: alpha[k], beta[k-1] (beta may be NULL when k == 1), x_norm (may be NULL), and, when Q is
+ * not NULL, Q[k*n] as k contiguous vectors -- the layout cu_decompose leaves on the host
+ * (&Q[k*n], cu_lanczos.cu:126) and multOut consumes with Qtrans = true
+ * (parallel-final/lib/multiplyOut.cu:42-44).  The basis also stays resident on the device for
+ * lzx_multout_f64.  No breakdown guard for beta_j == 0, as in the reference.
+ * With a communicator every rank must call it with the same arguments.                           */
+int lzx_lanczos_f64(lzx_handle h, const double *x0, uint32_t k, double *alpha, double *beta,
+                    double *Q, double *x_norm, lzx_stats *stats);
+/* The same over `world` handles wired with lzx_comm_init_local, driven by one host thread. */
+int lzx_lanczos_f64_local(lzx_handle *hs, int world, const double *x0, uint32_t k, double *alpha,
+                          double *beta, double *Q, double *x_norm, lzx_stats *stats);
+
+/* lzx_multout_f64: ans = Q t on the device-resident basis of the last decomposition (t[k] is
+ * V (e^lambda * ||x|| * V[0,:]) computed by the host as in parallel-final/lib/multiplyOut.cu:30-40;
+ * this call is the second dgemv, :42-46; cf. parallel-mult-on-card/lib/cu_multiplyOut.cu:66-71).
+ * ans[n] in the caller's vertex order, complete on every rank.                                   */
+int lzx_multout_f64(lzx_handle h, const double *t, uint32_t k, double *ans);
+int lzx_multout_f64_local(lzx_handle *hs, int world, const double *t, uint32_t k, double *ans);
+
+/* ---- measurement hook --------------------------------------------------------------------------
+ * Runs `reps` back-to-back SpMVs of the current graph on a device-resident vector and returns the
+ * average and minimum HIP-event time of one SpMV (all its kernels) in milliseconds.              */
+int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
+
+/* Tuning knobs (0 = default).  hub_entries: how many of the highest-degree vertices' x values each
+ * workgroup stages in LDS (0 disables staging when `set` is non-zero).                           */
+int lzx_set_option(lzx_handle h, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZX_H_ */

@@ -1,0 +1,265 @@
+"""ctypes face of liblzx.so (include/lzx.h) for the parity tests, bench.py and the smoke check.
+
+This is plumbing, not the product: the product is the C-ABI library built from csrc/ and the C++
+drop-in classes in host/.  There is no CPU fallback here -- if liblzx.so is missing or a call fails the
+error is raised; nothing in this package imports the test oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblzx.so")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_h = ctypes.c_void_p
+_hp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class LzxStats(ctypes.Structure):
+    _fields_ = [("loop_ms", ctypes.c_double), ("spmv_ms", ctypes.c_double),
+                ("spmv_ms_min", ctypes.c_double), ("vec_ms", ctypes.c_double),
+                ("comm_ms", ctypes.c_double), ("iters", ctypes.c_uint32),
+                ("spmv_kernels", ctypes.c_uint32), ("spmv_bytes", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class LzxGraphInfo(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint64), ("nnz", ctypes.c_uint64), ("max_degree", ctypes.c_uint64),
+                ("rows_local", ctypes.c_uint64), ("nnz_local", ctypes.c_uint64),
+                ("long_rows", ctypes.c_uint64), ("sell_padded", ctypes.c_uint64),
+                ("hub_entries", ctypes.c_uint32), ("world", ctypes.c_uint32), ("rank", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+# every symbol include/lzx.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("lzx_create", ctypes.c_int, [_hp, ctypes.c_int]),
+    ("lzx_destroy", None, [_h]),
+    ("lzx_last_error", ctypes.c_char_p, []),
+    ("lzx_comm_unique_id", ctypes.c_int, [_u8p]),
+    ("lzx_comm_init_rank", ctypes.c_int, [_h, _u8p, ctypes.c_int, ctypes.c_int]),
+    ("lzx_comm_init_local", ctypes.c_int, [_hp, ctypes.c_int]),
+    ("lzx_set_graph_csr", ctypes.c_int, [_h, ctypes.c_uint64, ctypes.c_uint64, _u64p, _u32p]),
+    ("lzx_set_graph_csr32", ctypes.c_int, [_h, ctypes.c_uint32, ctypes.c_uint32, _u32p, _u32p]),
+    ("lzx_set_graph_edges", ctypes.c_int, [_h, ctypes.c_uint64, ctypes.c_uint64, _u32p, _u32p]),
+    ("lzx_gen_graph", ctypes.c_int, [_h, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
+                                     ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    ("lzx_get_graph_info", ctypes.c_int, [_h, ctypes.POINTER(LzxGraphInfo)]),
+    ("lzx_get_graph_csr", ctypes.c_int, [_h, _u64p, _u32p]),
+    ("lzx_spmv_f64", ctypes.c_int, [_h, _f64p, _f64p]),
+    ("lzx_spmv_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, _f64p]),
+    ("lzx_lanczos_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p, _f64p, _f64p, _f64p,
+                                       ctypes.POINTER(LzxStats)]),
+    ("lzx_lanczos_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p, _f64p, _f64p,
+                                             _f64p, ctypes.POINTER(LzxStats)]),
+    ("lzx_multout_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
+    ("lzx_multout_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p]),
+    ("lzx_bench_spmv", ctypes.c_int, [_h, ctypes.c_uint32, _f64p, _f64p]),
+    ("lzx_set_option", ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int64]),
+]
+
+_LIB = None
+
+
+class LzxError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load liblzx.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise LzxError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C {_HERE})")
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise LzxError(f"{what} failed ({rc}): {lib().lzx_last_error().decode(errors='replace')}")
+
+
+def rmat_thresholds(a=0.57, b=0.19, c=0.19):
+    return int(round(a * 65536)), int(round((a + b) * 65536)), int(round((a + b + c) * 65536))
+
+
+class Engine:
+    """One lzx handle (one GPU)."""
+
+    def __init__(self, device: int = 0, **options):
+        self.h = ctypes.c_void_p()
+        _check(lib().lzx_create(ctypes.byref(self.h), device), "lzx_create")
+        for k, v in options.items():
+            self.set_option(k, v)
+        self.n = 0
+
+    def set_option(self, name: str, value: int):
+        _check(lib().lzx_set_option(self.h, name.encode(), int(value)), f"lzx_set_option({name})")
+
+    def close(self):
+        if self.h:
+            lib().lzx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- communicator ----
+    @staticmethod
+    def unique_id() -> np.ndarray:
+        uid = np.zeros(128, dtype=np.uint8)
+        _check(lib().lzx_comm_unique_id(_p(uid, _u8p)), "lzx_comm_unique_id")
+        return uid
+
+    def comm_init_rank(self, uid: np.ndarray, rank: int, world: int):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        _check(lib().lzx_comm_init_rank(self.h, _p(uid, _u8p), rank, world), "lzx_comm_init_rank")
+
+    # ---- graph ----
+    def set_graph_csr(self, row_ptr, col_idx):
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        n, nnz = len(row_ptr) - 1, len(col_idx)
+        ci = col_idx if nnz else np.zeros(1, dtype=np.uint32)
+        _check(lib().lzx_set_graph_csr(self.h, n, nnz, _p(row_ptr, _u64p), _p(ci, _u32p)), "lzx_set_graph_csr")
+        self.n = n
+
+    def set_graph_csr32(self, row_ptr, col_idx):
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        n, nnz = len(row_ptr) - 1, len(col_idx)
+        ci = col_idx if nnz else np.zeros(1, dtype=np.uint32)
+        _check(lib().lzx_set_graph_csr32(self.h, n, nnz, _p(row_ptr, _u32p), _p(ci, _u32p)), "lzx_set_graph_csr32")
+        self.n = n
+
+    def set_graph_edges(self, n, src, dst):
+        src = np.ascontiguousarray(src, dtype=np.uint32)
+        dst = np.ascontiguousarray(dst, dtype=np.uint32)
+        assert len(src) == len(dst)
+        s = src if len(src) else np.zeros(1, dtype=np.uint32)
+        d = dst if len(dst) else np.zeros(1, dtype=np.uint32)
+        _check(lib().lzx_set_graph_edges(self.h, n, len(src), _p(s, _u32p), _p(d, _u32p)), "lzx_set_graph_edges")
+        self.n = n
+
+    def gen_er(self, n, draws, seed):
+        _check(lib().lzx_gen_graph(self.h, 0, 0, n, draws, seed, 0, 0, 0), "lzx_gen_graph(er)")
+        self.n = n
+
+    def gen_rmat(self, scale, n, draws, seed, a=0.57, b=0.19, c=0.19):
+        ta, tab, tabc = rmat_thresholds(a, b, c)
+        _check(lib().lzx_gen_graph(self.h, 1, scale, n, draws, seed, ta, tab, tabc), "lzx_gen_graph(rmat)")
+        self.n = n
+
+    def info(self) -> dict:
+        gi = LzxGraphInfo()
+        _check(lib().lzx_get_graph_info(self.h, ctypes.byref(gi)), "lzx_get_graph_info")
+        return gi.as_dict()
+
+    def get_graph_csr(self):
+        gi = self.info()
+        rp = np.empty(gi["n"] + 1, dtype=np.uint64)
+        ci = np.empty(max(gi["nnz"], 1), dtype=np.uint32)
+        _check(lib().lzx_get_graph_csr(self.h, _p(rp, _u64p), _p(ci, _u32p)), "lzx_get_graph_csr")
+        return rp, ci[:gi["nnz"]]
+
+    # ---- hot path ----
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert len(x) == self.n
+        y = np.empty(self.n)
+        _check(lib().lzx_spmv_f64(self.h, _p(x, _f64p), _p(y, _f64p)), "lzx_spmv_f64")
+        return y
+
+    def lanczos(self, x0, k: int, want_q: bool = True):
+        """Returns (alpha[k], beta[k-1], Q (k, n) or None, x_norm, stats dict)."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        assert len(x0) == self.n
+        alpha = np.zeros(k)
+        beta = np.zeros(max(k - 1, 1))
+        Q = np.empty((k, self.n)) if want_q else None
+        xn = ctypes.c_double()
+        st = LzxStats()
+        _check(lib().lzx_lanczos_f64(self.h, _p(x0, _f64p), k, _p(alpha, _f64p), _p(beta, _f64p),
+                                     _p(Q, _f64p) if want_q else None, ctypes.byref(xn), ctypes.byref(st)),
+               "lzx_lanczos_f64")
+        return alpha, beta[:k - 1], Q, xn.value, st.as_dict()
+
+    def multout(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        ans = np.empty(self.n)
+        _check(lib().lzx_multout_f64(self.h, _p(t, _f64p), len(t), _p(ans, _f64p)), "lzx_multout_f64")
+        return ans
+
+    def bench_spmv(self, reps: int = 20):
+        avg, mn = ctypes.c_double(), ctypes.c_double()
+        _check(lib().lzx_bench_spmv(self.h, reps, ctypes.byref(avg), ctypes.byref(mn)), "lzx_bench_spmv")
+        return avg.value, mn.value
+
+
+class LocalGroup:
+    """`world` handles wired as an in-process communicator (lzx_comm_init_local)."""
+
+    def __init__(self, devices, **options):
+        self.engines = [Engine(d, **options) for d in devices]
+        self.world = len(devices)
+        self.arr = (ctypes.c_void_p * self.world)(*[e.h for e in self.engines])
+        _check(lib().lzx_comm_init_local(self.arr, self.world), "lzx_comm_init_local")
+        self.n = 0
+
+    def set_graph_csr(self, row_ptr, col_idx):
+        for e in self.engines:
+            e.set_graph_csr(row_ptr, col_idx)
+        self.n = self.engines[0].n
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.n)
+        _check(lib().lzx_spmv_f64_local(self.arr, self.world, _p(x, _f64p), _p(y, _f64p)), "lzx_spmv_f64_local")
+        return y
+
+    def lanczos(self, x0, k: int, want_q: bool = True):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        alpha = np.zeros(k)
+        beta = np.zeros(max(k - 1, 1))
+        Q = np.empty((k, self.n)) if want_q else None
+        xn = ctypes.c_double()
+        st = LzxStats()
+        _check(lib().lzx_lanczos_f64_local(self.arr, self.world, _p(x0, _f64p), k, _p(alpha, _f64p),
+                                           _p(beta, _f64p), _p(Q, _f64p) if want_q else None,
+                                           ctypes.byref(xn), ctypes.byref(st)), "lzx_lanczos_f64_local")
+        return alpha, beta[:k - 1], Q, xn.value, st.as_dict()
+
+    def multout(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        ans = np.empty(self.n)
+        _check(lib().lzx_multout_f64_local(self.arr, self.world, _p(t, _f64p), len(t), _p(ans, _f64p)),
+               "lzx_multout_f64_local")
+        return ans
+
+    def close(self):
+        for e in self.engines:
+            e.close()

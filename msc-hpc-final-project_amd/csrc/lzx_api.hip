@@ -1,0 +1,458 @@
+// lzx_api.hip -- C ABI entry points (include/lzx.h) and the Lanczos loop driver.
+//
+// The loop is written once over a list of handles: one handle (single GPU, or one rank of an RCCL
+// communicator) or all handles of an in-process communicator.  Everything between the upload of x0
+// and the download of alpha/beta is enqueued on HIP streams without a host synchronisation; the
+// scalars alpha_j / beta_j never leave the device (as in the reference, where later kernels read
+// *alpha_d: parallel-final/lib/cu_lanczos.cu:108,113,123).
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "lzx_internal.h"
+
+static thread_local std::string g_err;
+
+void lzx_set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char *lzx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lzx_create(lzx_handle *out, int device_id)
+{
+    if (!out) LZX_FAIL(LZX_ERR_ARG, "lzx_create: null out");
+    *out = nullptr;
+    int count = 0;
+    LZX_HIP(hipGetDeviceCount(&count));
+    if (device_id < 0 || device_id >= count)
+        LZX_FAIL(LZX_ERR_ARG, "lzx_create: device %d not present (%d visible)", device_id, count);
+    LZX_HIP(hipSetDevice(device_id));
+    lzx_ctx *c = new (std::nothrow) lzx_ctx;
+    if (!c) LZX_FAIL(LZX_ERR_NOMEM, "lzx_create: host allocation failed");
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_a);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_b);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_scal), sizeof(double) * (8 + 64));
+    if (e != hipSuccess) {
+        lzx_set_error("lzx_create: %s", hipGetErrorString(e));
+        lzx_destroy(c);
+        return LZX_ERR_HIP;
+    }
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return LZX_OK;
+}
+
+extern "C" void lzx_destroy(lzx_handle c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    lzx_graph_release(c);
+    lzx_comm_release(c);
+    if (c->d_alpha) (void)hipFree(c->d_alpha);
+    if (c->d_beta) (void)hipFree(c->d_beta);
+    if (c->d_scal) (void)hipFree(c->d_scal);
+    for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->ev_phase) (void)hipEventDestroy(c->ev_phase);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
+{
+    if (!c || !name) LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: bad argument");
+    if (c->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "options must be set before the graph is handed over");
+    if (!strcmp(name, "hub_entries")) c->hub_opt = value;
+    else if (!strcmp(name, "wgs_per_cu")) c->wgs_per_cu_opt = value;
+    else if (!strcmp(name, "nt_index_loads")) c->nt_opt = value;
+    else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
+    return LZX_OK;
+}
+
+// --------------------------------------------------------------------------------------------------
+static int gather_handles(lzx_handle h, std::vector<lzx_ctx *> &cs)
+{
+    if (!h) LZX_FAIL(LZX_ERR_ARG, "null handle");
+    if (h->comm_kind == 1 && h->world > 1)
+        LZX_FAIL(LZX_ERR_STATE, "handle belongs to an in-process communicator: use the *_local entry point");
+    cs.assign(1, h);
+    return LZX_OK;
+}
+
+static int gather_handles_local(lzx_handle *hs, int world, std::vector<lzx_ctx *> &cs)
+{
+    if (!hs || world < 1) LZX_FAIL(LZX_ERR_ARG, "bad handle list");
+    cs.clear();
+    for (int p = 0; p < world; ++p) {
+        if (!hs[p]) LZX_FAIL(LZX_ERR_ARG, "null handle in list");
+        if (hs[p]->world != world || hs[p]->rank != p || (world > 1 && hs[p]->comm_kind != 1))
+            LZX_FAIL(LZX_ERR_STATE, "handles are not wired as an in-process communicator of %d", world);
+        cs.push_back(hs[p]);
+    }
+    return LZX_OK;
+}
+
+static int check_graphs(std::vector<lzx_ctx *> &cs)
+{
+    for (lzx_ctx *c : cs) {
+        if (!c->d_row_ptr || !c->d_v) LZX_FAIL(LZX_ERR_STATE, "no graph has been handed over");
+        if (c->n != cs[0]->n || c->nnz != cs[0]->nnz) LZX_FAIL(LZX_ERR_STATE, "handles hold different graphs");
+    }
+    return LZX_OK;
+}
+
+static int sync_all(std::vector<lzx_ctx *> &cs)
+{
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        LZX_HIP(hipStreamSynchronize(c->stream));
+    }
+    return LZX_OK;
+}
+
+static int ensure_capacity(lzx_ctx *c, u32 k)
+{
+    LZX_HIP(hipSetDevice(c->device));
+    if (k > c->k_cap) {
+        if (c->d_alpha) (void)hipFree(c->d_alpha);
+        if (c->d_beta) (void)hipFree(c->d_beta);
+        c->d_alpha = c->d_beta = nullptr;
+        c->k_cap = 0;
+        LZX_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_alpha), sizeof(double) * k));
+        LZX_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_beta), sizeof(double) * k));
+        c->k_cap = k;
+    }
+    if (k > c->q_cols) {
+        if (c->d_Q) (void)hipFree(c->d_Q);
+        c->d_Q = nullptr;
+        c->q_cols = 0;
+        LZX_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_Q), sizeof(double) * (size_t)k * c->ldq));
+        c->q_cols = k;
+    }
+    return LZX_OK;
+}
+
+// timing marks on the first handle's stream: the interval that ENDS at a mark is billed to its category
+enum { CAT_NONE = 0, CAT_SPMV = 1, CAT_VEC = 2, CAT_COMM = 3 };
+struct Marks {
+    lzx_ctx *c;
+    size_t used = 0;
+    std::vector<int> cat;
+    int tick(int category)
+    {
+        LZX_HIP(hipSetDevice(c->device));
+        if (used == c->ev_pool.size()) {
+            hipEvent_t ev;
+            LZX_HIP(hipEventCreate(&ev));
+            c->ev_pool.push_back(ev);
+        }
+        LZX_HIP(hipEventRecord(c->ev_pool[used], c->stream));
+        cat.push_back(category);
+        ++used;
+        return LZX_OK;
+    }
+};
+
+static u64 spmv_algorithmic_bytes(const lzx_ctx *c)
+{
+    // column indices once, row pointers once (W_p = 4), every x element once, y written once.
+    return 4ull * c->nnz_local + 4ull * ((u64)c->n_loc_real + 1) + 8ull * c->n + 8ull * c->n_loc_real;
+}
+
+static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, double *alpha, double *beta,
+                       double *Q, double *x_norm_out, lzx_stats *stats)
+{
+    if (!x0 || !alpha || k == 0 || (k > 1 && !beta)) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_f64: bad argument");
+    LZX_TRY(check_graphs(cs));
+    lzx_ctx *c0 = cs[0];
+    const u64 n = c0->n;
+    const int world = c0->world;
+    const bool multi = world > 1;
+
+    // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161).
+    double ss = 0.0;
+    for (u64 i = 0; i < n; ++i) ss += x0[i] * x0[i];
+    const double x_norm = std::sqrt(ss);
+    if (x_norm_out) *x_norm_out = x_norm;
+
+    for (lzx_ctx *c : cs) {
+        LZX_TRY(ensure_capacity(c, k));
+        c->k_last = 0;
+        LZX_HIP(hipMemsetAsync(c->d_Q, 0, sizeof(double) * (size_t)k * c->ldq, c->stream));
+        LZX_HIP(hipMemcpyAsync(c->d_io, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        // q_0 = x0 / ||x0|| (serial/lib/lanczos.cc:16-17), scattered into the internal order
+        if (!multi) {
+            LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_Q, x_norm));
+        } else {
+            LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_xbuf, x_norm));
+            LZX_HIP(hipMemcpyAsync(c->d_Q, c->d_xbuf + (size_t)c->rank * c->n_loc_pad,
+                                   sizeof(double) * c->n_loc_pad, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    LZX_TRY(sync_all(cs));
+
+    Marks mk{c0};
+    LZX_HIP(hipSetDevice(c0->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    LZX_TRY(mk.tick(CAT_NONE));
+
+    std::vector<const double *> src(cs.size());
+    std::vector<double *> dst(cs.size());
+    const u32 np = lzx_spmv_partials(c0);
+
+    for (u32 j = 0; j < k; ++j) {
+        // v = A q_j ; partials of alpha_j
+        for (lzx_ctx *c : cs) {
+            LZX_HIP(hipSetDevice(c->device));
+            const double *qj = c->d_Q + (size_t)j * c->ldq;
+            SpmvLaunch l{multi ? c->d_xbuf : qj, qj, c->d_v, c->d_partials};
+            LZX_TRY(lzx_launch_spmv(c, l));
+        }
+        LZX_TRY(mk.tick(CAT_SPMV));
+
+        if (multi) {
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_TRY(lzx_launch_reduce(c, c->d_partials, lzx_spmv_partials(c), c->d_scal + 0, 0));
+            }
+            LZX_TRY(lzx_comm_allreduce_sum(cs, 0));
+            LZX_TRY(mk.tick(CAT_COMM));
+        }
+
+        if (j == k - 1) {
+            // last step: only alpha_{k-1} is an output (the reference also updates v, then drops it)
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                if (multi) LZX_HIP(hipMemcpyAsync(c->d_alpha + j, c->d_scal + 0, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                else LZX_TRY(lzx_launch_reduce(c, c->d_partials, np, c->d_alpha + j, 0));
+            }
+            LZX_TRY(mk.tick(CAT_VEC));
+            break;
+        }
+
+        u32 np2 = 0;
+        for (lzx_ctx *c : cs) {
+            LZX_HIP(hipSetDevice(c->device));
+            const double *qj = c->d_Q + (size_t)j * c->ldq;
+            const double *qjm1 = j > 0 ? c->d_Q + (size_t)(j - 1) * c->ldq : nullptr;
+            LZX_TRY(lzx_launch_axpy_norm(c, c->d_v, qj, qjm1, multi ? c->d_scal + 0 : c->d_partials,
+                                         multi ? 1 : lzx_spmv_partials(c), c->d_alpha + j,
+                                         j > 0 ? c->d_beta + (j - 1) : nullptr, c->d_partials2, &np2));
+        }
+        LZX_TRY(mk.tick(CAT_VEC));
+
+        if (multi) {
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_TRY(lzx_launch_reduce(c, c->d_partials2, np2, c->d_scal + 1, 0));
+            }
+            LZX_TRY(lzx_comm_allreduce_sum(cs, 1));
+            LZX_TRY(mk.tick(CAT_COMM));
+        }
+
+        for (lzx_ctx *c : cs) {
+            LZX_HIP(hipSetDevice(c->device));
+            LZX_TRY(lzx_launch_scale(c, c->d_v, c->d_Q + (size_t)(j + 1) * c->ldq,
+                                     multi ? c->d_scal + 1 : c->d_partials2, multi ? 1 : np2, c->d_beta + j));
+        }
+        LZX_TRY(mk.tick(CAT_VEC));
+
+        if (multi) {
+            for (size_t i = 0; i < cs.size(); ++i) {
+                src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
+                dst[i] = cs[i]->d_xbuf;
+            }
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+            LZX_HIP(hipSetDevice(c0->device));
+            LZX_TRY(mk.tick(CAT_COMM));
+        }
+    }
+    LZX_TRY(sync_all(cs));
+    const auto t1 = std::chrono::steady_clock::now();
+    for (lzx_ctx *c : cs) c->k_last = k;
+
+    // ---- outputs ----
+    LZX_HIP(hipSetDevice(c0->device));
+    LZX_HIP(hipMemcpy(alpha, c0->d_alpha, sizeof(double) * k, hipMemcpyDeviceToHost));
+    if (k > 1) LZX_HIP(hipMemcpy(beta, c0->d_beta, sizeof(double) * (k - 1), hipMemcpyDeviceToHost));
+
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->loop_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        stats->iters = k;
+        stats->spmv_kernels = 1 + (c0->fin_grid > 0 ? 1 : 0);
+        stats->spmv_bytes = spmv_algorithmic_bytes(c0);
+        stats->spmv_ms_min = 1e300;
+        for (size_t i = 1; i < mk.used; ++i) {
+            float ms = 0.f;
+            LZX_HIP(hipEventElapsedTime(&ms, c0->ev_pool[i - 1], c0->ev_pool[i]));
+            switch (mk.cat[i]) {
+                case CAT_SPMV: stats->spmv_ms += ms; if (ms < stats->spmv_ms_min) stats->spmv_ms_min = ms; break;
+                case CAT_VEC: stats->vec_ms += ms; break;
+                case CAT_COMM: stats->comm_ms += ms; break;
+                default: break;
+            }
+        }
+        if (stats->spmv_ms_min == 1e300) stats->spmv_ms_min = 0.0;
+    }
+
+    if (Q) {
+        // k contiguous vectors in the caller's vertex order (cu_lanczos.cu:126 layout)
+        for (u32 j = 0; j < k; ++j) {
+            if (multi) {
+                for (size_t i = 0; i < cs.size(); ++i) {
+                    src[i] = cs[i]->d_Q + (size_t)j * cs[i]->ldq;
+                    dst[i] = cs[i]->d_ybuf;
+                }
+                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+            }
+            LZX_HIP(hipSetDevice(c0->device));
+            LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_Q + (size_t)j * c0->ldq, c0->d_io));
+            LZX_HIP(hipMemcpyAsync(Q + (size_t)j * n, c0->d_io, sizeof(double) * n, hipMemcpyDeviceToHost, c0->stream));
+            LZX_TRY(sync_all(cs));
+        }
+    }
+    return LZX_OK;
+}
+
+extern "C" int lzx_lanczos_f64(lzx_handle h, const double *x0, uint32_t k, double *alpha, double *beta,
+                               double *Q, double *x_norm, lzx_stats *stats)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    return lanczos_run(cs, x0, k, alpha, beta, Q, x_norm, stats);
+}
+
+extern "C" int lzx_lanczos_f64_local(lzx_handle *hs, int world, const double *x0, uint32_t k, double *alpha,
+                                     double *beta, double *Q, double *x_norm, lzx_stats *stats)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles_local(hs, world, cs));
+    return lanczos_run(cs, x0, k, alpha, beta, Q, x_norm, stats);
+}
+
+// --------------------------------------------------------------------------------------------------
+static int spmv_run(std::vector<lzx_ctx *> &cs, const double *x, double *y)
+{
+    if (!x || !y) LZX_FAIL(LZX_ERR_ARG, "lzx_spmv_f64: bad argument");
+    LZX_TRY(check_graphs(cs));
+    lzx_ctx *c0 = cs[0];
+    const bool multi = c0->world > 1;
+    std::vector<const double *> src(cs.size());
+    std::vector<double *> dst(cs.size());
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        LZX_HIP(hipMemcpyAsync(c->d_io, x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+        LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_xbuf, 1.0));
+        SpmvLaunch l{c->d_xbuf, c->d_xbuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
+        LZX_TRY(lzx_launch_spmv(c, l));
+    }
+    if (multi) {
+        for (size_t i = 0; i < cs.size(); ++i) { src[i] = cs[i]->d_v; dst[i] = cs[i]->d_ybuf; }
+        LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+    }
+    LZX_HIP(hipSetDevice(c0->device));
+    LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_v, c0->d_io));
+    LZX_HIP(hipMemcpyAsync(y, c0->d_io, sizeof(double) * c0->n, hipMemcpyDeviceToHost, c0->stream));
+    return sync_all(cs);
+}
+
+extern "C" int lzx_spmv_f64(lzx_handle h, const double *x, double *y)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    return spmv_run(cs, x, y);
+}
+
+extern "C" int lzx_spmv_f64_local(lzx_handle *hs, int world, const double *x, double *y)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles_local(hs, world, cs));
+    return spmv_run(cs, x, y);
+}
+
+// --------------------------------------------------------------------------------------------------
+static int multout_run(std::vector<lzx_ctx *> &cs, const double *t, u32 k, double *ans)
+{
+    if (!t || !ans || k == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_multout_f64: bad argument");
+    LZX_TRY(check_graphs(cs));
+    lzx_ctx *c0 = cs[0];
+    const bool multi = c0->world > 1;
+    for (lzx_ctx *c : cs)
+        if (c->k_last < k) LZX_FAIL(LZX_ERR_STATE, "lzx_multout_f64: the resident basis has %u vectors, %u asked", c->k_last, k);
+    std::vector<const double *> src(cs.size());
+    std::vector<double *> dst(cs.size());
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        // the k coefficients are staged in the (idle) block-partials buffer
+        if (k > c->np_cap) LZX_FAIL(LZX_ERR_LIMIT, "k = %u exceeds the staging capacity %u", k, c->np_cap);
+        LZX_HIP(hipMemcpyAsync(c->d_partials, t, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+        LZX_TRY(lzx_launch_multout(c, c->d_partials, k, c->d_v));
+    }
+    if (multi) {
+        for (size_t i = 0; i < cs.size(); ++i) { src[i] = cs[i]->d_v; dst[i] = cs[i]->d_ybuf; }
+        LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+    }
+    LZX_HIP(hipSetDevice(c0->device));
+    LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_v, c0->d_io));
+    LZX_HIP(hipMemcpyAsync(ans, c0->d_io, sizeof(double) * c0->n, hipMemcpyDeviceToHost, c0->stream));
+    return sync_all(cs);
+}
+
+extern "C" int lzx_multout_f64(lzx_handle h, const double *t, uint32_t k, double *ans)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    return multout_run(cs, t, k, ans);
+}
+
+extern "C" int lzx_multout_f64_local(lzx_handle *hs, int world, const double *t, uint32_t k, double *ans)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles_local(hs, world, cs));
+    return multout_run(cs, t, k, ans);
+}
+
+// --------------------------------------------------------------------------------------------------
+extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, double *min_ms)
+{
+    if (!c || reps == 0 || !avg_ms) LZX_FAIL(LZX_ERR_ARG, "lzx_bench_spmv: bad argument");
+    if (!c->d_row_ptr || !c->d_v) LZX_FAIL(LZX_ERR_STATE, "no graph has been handed over");
+    LZX_HIP(hipSetDevice(c->device));
+    // a non-trivial resident input: x = 1 everywhere
+    std::vector<double> ones(c->n, 1.0);
+    LZX_HIP(hipMemcpyAsync(c->d_io, ones.data(), sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
+    LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_xbuf, 1.0));
+    SpmvLaunch l{c->d_xbuf, c->d_xbuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
+    LZX_TRY(lzx_launch_spmv(c, l));  // warm-up
+    LZX_HIP(hipStreamSynchronize(c->stream));
+    double total = 0.0, best = 1e300;
+    for (u32 r = 0; r < reps; ++r) {
+        LZX_HIP(hipEventRecord(c->ev_a, c->stream));
+        LZX_TRY(lzx_launch_spmv(c, l));
+        LZX_HIP(hipEventRecord(c->ev_b, c->stream));
+        LZX_HIP(hipEventSynchronize(c->ev_b));
+        float ms = 0.f;
+        LZX_HIP(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+        total += ms;
+        if (ms < best) best = ms;
+    }
+    *avg_ms = total / reps;
+    if (min_ms) *min_ms = best;
+    return LZX_OK;
+}

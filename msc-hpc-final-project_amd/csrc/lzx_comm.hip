@@ -1,0 +1,208 @@
+// lzx_comm.hip -- the per-iteration exchange of the row-partitioned Lanczos loop.
+//
+// Two transports behind the same two operations (sum one double across ranks; all-gather the owned
+// slices of a vector into every rank's full-length copy):
+//   * RCCL (one process per GPU, xGMI): ncclAllReduce on 1 double, ncclAllGather of n_loc_pad doubles.
+//     librccl.so.1 is resolved with dlopen at communicator creation, so liblzx.so itself loads on a
+//     machine without RCCL and shares the copy a host program (e.g. PyTorch) may already have loaded.
+//   * local (all handles in one process -- the reference's two-cards model generalised,
+//     parallel-two-cards/lib/cu_lanczos.cu:125,158): device-to-device copies ordered by events.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "lzx_internal.h"
+
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return LZX_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *nm : names) {
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) LZX_FAIL(LZX_ERR_COMM, "cannot load librccl: %s", dlerror());
+#define SYM(field, name)                                                              \
+    do {                                                                              \
+        *reinterpret_cast<void **>(&g_rccl.field) = dlsym(lib, name);                 \
+        if (!g_rccl.field) LZX_FAIL(LZX_ERR_COMM, "librccl lacks symbol %s", name);   \
+    } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.lib = lib;
+    return LZX_OK;
+}
+
+#define LZX_NCCL(call)                                                                        \
+    do {                                                                                      \
+        ncclResult_t r_ = (call);                                                             \
+        if (r_ != ncclSuccess)                                                                \
+            LZX_FAIL(LZX_ERR_COMM, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+__global__ void k_sum_ranks(const double *vals, int world, double *out)
+{
+    double s = 0.0;
+    for (int p = 0; p < world; ++p) s += vals[p];  // rank order: fixed
+    *out = s;
+}
+}  // namespace
+
+extern "C" int lzx_comm_unique_id(uint8_t id[128])
+{
+    if (!id) LZX_FAIL(LZX_ERR_ARG, "lzx_comm_unique_id: null id");
+    LZX_TRY(rccl_load());
+    ncclUniqueId u;
+    LZX_NCCL(g_rccl.GetUniqueId(&u));
+    static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id, &u, 128);
+    return LZX_OK;
+}
+
+extern "C" int lzx_comm_init_rank(lzx_handle c, const uint8_t id[128], int rank, int world)
+{
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) LZX_FAIL(LZX_ERR_ARG, "lzx_comm_init_rank: bad argument");
+    if (c->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "wire the communicator before handing over the graph");
+    if (c->comm_kind != 0) LZX_FAIL(LZX_ERR_STATE, "handle already has a communicator");
+    LZX_TRY(rccl_load());
+    LZX_HIP(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclComm_t comm = nullptr;
+    LZX_NCCL(g_rccl.CommInitRank(&comm, world, u, rank));
+    c->nccl_comm = comm;
+    c->comm_kind = 2;
+    c->world = world;
+    c->rank = rank;
+    return LZX_OK;
+}
+
+extern "C" int lzx_comm_init_local(lzx_handle *hs, int world)
+{
+    if (!hs || world < 1) LZX_FAIL(LZX_ERR_ARG, "lzx_comm_init_local: bad argument");
+    for (int p = 0; p < world; ++p) {
+        if (!hs[p]) LZX_FAIL(LZX_ERR_ARG, "lzx_comm_init_local: null handle");
+        if (hs[p]->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "wire the communicator before handing over the graph");
+        if (hs[p]->comm_kind != 0) LZX_FAIL(LZX_ERR_STATE, "handle already has a communicator");
+    }
+    for (int p = 0; p < world; ++p) {
+        lzx_ctx *c = hs[p];
+        c->peers = new lzx_ctx *[world];
+        for (int q = 0; q < world; ++q) c->peers[q] = hs[q];
+        c->comm_kind = 1;
+        c->world = world;
+        c->rank = p;
+        // peers on other GPUs: let copies go straight over xGMI where the platform allows it
+        for (int q = 0; q < world; ++q) {
+            if (hs[q]->device == c->device) continue;
+            (void)hipSetDevice(c->device);
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, c->device, hs[q]->device) == hipSuccess && can) {
+                hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+    }
+    return LZX_OK;
+}
+
+void lzx_comm_release(lzx_ctx *c)
+{
+    if (c->comm_kind == 2 && c->nccl_comm && g_rccl.CommDestroy) {
+        (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
+    }
+    c->nccl_comm = nullptr;
+    delete[] c->peers;
+    c->peers = nullptr;
+    c->comm_kind = 0;
+    c->world = 1;
+    c->rank = 0;
+}
+
+// Make every stream in cs wait for everything queued so far on every other stream in cs.
+static int cross_barrier(std::vector<lzx_ctx *> &cs)
+{
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        LZX_HIP(hipEventRecord(c->ev_phase, c->stream));
+    }
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        for (lzx_ctx *p : cs)
+            if (p != c) LZX_HIP(hipStreamWaitEvent(c->stream, p->ev_phase, 0));
+    }
+    return LZX_OK;
+}
+
+// d_scal[slot] <- sum over ranks of d_scal[slot], on every handle.
+int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot)
+{
+    lzx_ctx *c0 = cs[0];
+    if (c0->world == 1) return LZX_OK;
+    if (c0->comm_kind == 2) {
+        LZX_NCCL(g_rccl.AllReduce(c0->d_scal + slot, c0->d_scal + slot, 1, ncclDouble, ncclSum,
+                                  static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
+        return LZX_OK;
+    }
+    // local: rank 0 collects, sums in rank order, hands the total back
+    const int world = c0->world;
+    if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
+    LZX_TRY(cross_barrier(cs));
+    LZX_HIP(hipSetDevice(c0->device));
+    for (int p = 0; p < world; ++p)
+        LZX_HIP(hipMemcpyAsync(c0->d_scal + 8 + p, cs[p]->d_scal + slot, sizeof(double), hipMemcpyDefault, c0->stream));
+    hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(1), 0, c0->stream, c0->d_scal + 8, world, c0->d_scal + slot);
+    for (int p = 1; p < world; ++p)
+        LZX_HIP(hipMemcpyAsync(cs[p]->d_scal + slot, c0->d_scal + slot, sizeof(double), hipMemcpyDefault, c0->stream));
+    LZX_TRY(cross_barrier(cs));
+    return LZX_OK;
+}
+
+// dst_full[i][p * n_loc_pad ...] <- src_loc[p][0 .. n_loc_pad) for every rank p, on every handle i.
+int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full)
+{
+    lzx_ctx *c0 = cs[0];
+    const size_t cnt = c0->n_loc_pad;
+    if (c0->world == 1) {
+        if (dst_full[0] != src_loc[0])
+            LZX_HIP(hipMemcpyAsync(dst_full[0], src_loc[0], cnt * sizeof(double), hipMemcpyDeviceToDevice, c0->stream));
+        return LZX_OK;
+    }
+    if (c0->comm_kind == 2) {
+        LZX_NCCL(g_rccl.AllGather(src_loc[0], dst_full[0], cnt, ncclDouble,
+                                  static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
+        return LZX_OK;
+    }
+    const int world = c0->world;
+    if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
+    LZX_TRY(cross_barrier(cs));
+    for (int i = 0; i < world; ++i) {
+        LZX_HIP(hipSetDevice(cs[i]->device));
+        for (int p = 0; p < world; ++p) {
+            double *dst = dst_full[i] + (size_t)p * cnt;
+            if (dst == src_loc[p]) continue;
+            LZX_HIP(hipMemcpyAsync(dst, src_loc[p], cnt * sizeof(double), hipMemcpyDefault, cs[i]->stream));
+        }
+    }
+    LZX_TRY(cross_barrier(cs));
+    return LZX_OK;
+}

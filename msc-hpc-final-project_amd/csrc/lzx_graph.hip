@@ -1,0 +1,535 @@
+// lzx_graph.hip -- graph hand-over and the one-time reshaping of the caller's CSR into the layout the
+// SpMV kernel streams:
+//   1. vertices are ranked by degree (descending, ties by caller's id) with a device radix sort;
+//   2. degree rank r is owned by rank r % world at local row r / world, so every rank holds the same
+//      mix of heavy and light rows and local rows are again sorted by degree;
+//   3. local rows with more than LZX_LONG_ROW entries become "split rows" (wave-sized items);
+//      the rest form a sliced-ELL body with 64-row slices whose width is the slice's first (largest)
+//      degree -- almost no padding because neighbours in the order have near-equal degree;
+//   4. column indices are rewritten to codes: c < hub means "x value staged in LDS slot c" (the hub
+//      highest-degree vertices), otherwise hub + position in the full-length exchange layout.
+// Within a row the caller's ascending column order is kept, so the body reproduces the reference's
+// summation order exactly (serial/lib/SPMV.cc:24-27).
+//
+// Also here: device-side ingest of an edge list (replaces the std::set build of
+// adjMatrix::populate_sparse_matrix, parallel-final/lib/adjMatrix.cc:21-46) and the seeded ER / R-MAT
+// generators used by bench.py (integer spec shared with oracle/lanczos_oracle.c).
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "lzx_internal.h"
+
+template <typename T>
+static int dev_alloc(T **p, u64 count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    LZX_HIP(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return LZX_OK;
+}
+
+template <typename T>
+static void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int lzx_graph_release(lzx_ctx *c)
+{
+    dev_free(c->d_row_ptr);
+    dev_free(c->d_col_idx);
+    dev_free(c->d_gidx_of_old);
+    dev_free(c->d_slice_off);
+    dev_free(c->d_slice_w);
+    dev_free(c->d_sell_cols);
+    dev_free(c->d_long_cols);
+    dev_free(c->d_item_beg);
+    dev_free(c->d_item_len);
+    dev_free(c->d_item_first);
+    dev_free(c->d_long_partial);
+    dev_free(c->d_v);
+    dev_free(c->d_Q);
+    dev_free(c->d_xbuf);
+    dev_free(c->d_ybuf);
+    dev_free(c->d_io);
+    dev_free(c->d_partials);
+    dev_free(c->d_partials2);
+    c->q_cols = 0;
+    c->k_last = 0;
+    c->n = c->nnz = 0;
+    return LZX_OK;
+}
+
+// --------------------------------------------------------------------------------------------------
+// kernels of the reshaping pass
+__global__ void k_degrees(const u64 *row_ptr, u32 *deg, u32 *ids, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        deg[i] = (u32)(row_ptr[i + 1] - row_ptr[i]);
+        ids[i] = (u32)i;
+    }
+}
+
+// degree rank r -> position in the exchange layout and column code
+__global__ void k_rank_maps(const u32 *sorted_ids, u32 *gidx_of_old, u32 *code_of_old, u64 n,
+                            u32 world, u32 n_loc_pad, u32 hub)
+{
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u32 o = sorted_ids[r];
+    const u32 g = (u32)(r % world) * n_loc_pad + (u32)(r / world);
+    gidx_of_old[o] = g;
+    code_of_old[o] = (r < hub) ? (u32)r : hub + g;
+}
+
+// local row l <-> degree rank l * world + rank
+__global__ void k_local_rows(const u32 *sorted_ids, const u32 *sorted_deg, u32 *old_of_local,
+                             u32 *deg_local, u32 n_loc_real, u32 world, u32 rank)
+{
+    const u32 l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_loc_real) return;
+    const u64 r = (u64)l * world + rank;
+    old_of_local[l] = sorted_ids[r];
+    deg_local[l] = sorted_deg[r];
+}
+
+// Body: thread = local row; writes its row's codes as 16-byte packets, packet p of lane l of slice s
+// at ((uint4*)(cols + slice_off[s]))[p * 64 + l].
+__global__ void k_fill_sell(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old,
+                            const u32 *old_of_local, const u32 *deg_local, u32 n_loc_real, u32 row0,
+                            u32 n_loc_pad, const u64 *slice_off, const u32 *slice_w, u32 *cols,
+                            u32 sentinel)
+{
+    const u32 l = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_loc_pad) return;
+    const u32 s = (l - row0) >> 6, lane = (l - row0) & 63;
+    const u32 w = slice_w[s];
+    uint4 *out = reinterpret_cast<uint4 *>(cols + slice_off[s]) + lane;
+    u32 d = 0;
+    u64 base = 0;
+    if (l < n_loc_real) {
+        d = deg_local[l];
+        base = row_ptr[old_of_local[l]];
+    }
+    for (u32 k = 0; k < w; k += 4) {
+        uint4 c;
+        c.x = (k + 0 < d) ? code_of_old[col_idx[base + k + 0]] : sentinel;
+        c.y = (k + 1 < d) ? code_of_old[col_idx[base + k + 1]] : sentinel;
+        c.z = (k + 2 < d) ? code_of_old[col_idx[base + k + 2]] : sentinel;
+        c.w = (k + 3 < d) ? code_of_old[col_idx[base + k + 3]] : sentinel;
+        out[(size_t)(k >> 2) * 64] = c;
+    }
+}
+
+// Split rows: one wavefront per row copies (and recodes) its entries contiguously, padded to 4.
+__global__ void k_fill_long(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old,
+                            const u32 *old_of_local, const u32 *deg_local, u32 n_loc_real,
+                            const u64 *long_ptr, u32 *long_cols, u32 sentinel)
+{
+    const u32 r = blockIdx.x;
+    const u64 beg = long_ptr[r], end = long_ptr[r + 1];
+    u32 d = 0;
+    u64 base = 0;
+    if (r < n_loc_real) {
+        d = deg_local[r];
+        base = row_ptr[old_of_local[r]];
+    }
+    for (u64 k = threadIdx.x; k < end - beg; k += blockDim.x)
+        long_cols[beg + k] = (k < d) ? code_of_old[col_idx[base + k]] : sentinel;
+}
+
+static u32 round_up(u32 a, u32 m) { return (a + m - 1) / m * m; }
+
+int lzx_graph_prepare(lzx_ctx *c)
+{
+    const u64 n = c->n;
+    const u32 world = (u32)c->world, rank = (u32)c->rank;
+    if (n == 0) LZX_FAIL(LZX_ERR_ARG, "graph has no vertices");
+    if (n >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "n = %llu: this build indexes vertices with 31 bits", (unsigned long long)n);
+    if (c->nnz >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "nnz = %llu >= 2^32 is not supported yet", (unsigned long long)c->nnz);
+
+    hipStream_t st = c->stream;
+    const u32 per = (u32)((n + world - 1) / world);
+    c->n_loc_pad = round_up(per, LZX_SLICE);
+    c->ldq = c->n_loc_pad + LZX_TAIL;
+    c->xlen = (u64)world * c->n_loc_pad + LZX_TAIL;
+    c->n_loc_real = (rank < n) ? (u32)((n - rank + world - 1) / world) : 0;
+    if (c->xlen + 65536 >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "exchange layout does not fit 32-bit codes");
+
+    // hub entries staged in LDS: default 8192 (64 KiB -> two 1024-thread workgroups per CU)
+    u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : 8192;
+    hub = std::min<u64>(hub, n);
+    hub = std::min<u64>(hub, 20000);  // 160 KiB LDS per CU
+    hub &= ~1ull;
+    c->hub = (u32)hub;
+    c->spmv_lds = ((size_t)c->hub + LZX_SPMV_BLOCK / 64) * sizeof(double);
+    const u32 sentinel = c->hub + (u32)((u64)world * c->n_loc_pad);
+
+    // ---- 1. degree ranking ----
+    u32 *d_deg = nullptr, *d_ids = nullptr, *d_sdeg = nullptr, *d_sids = nullptr, *d_code = nullptr;
+    u32 *d_old_of_local = nullptr, *d_deg_local = nullptr;
+    void *d_tmp = nullptr;
+    u64 *d_long_ptr = nullptr;
+    int rc = LZX_OK;
+    std::vector<u32> degl;
+    std::vector<u64> h_slice_off, h_long_ptr, h_item_beg;
+    std::vector<u32> h_slice_w, h_item_len, h_item_first;
+    auto cleanup = [&]() {
+        dev_free(d_deg); dev_free(d_ids); dev_free(d_sdeg); dev_free(d_sids); dev_free(d_code);
+        dev_free(d_old_of_local); dev_free(d_deg_local); dev_free(d_long_ptr);
+        if (d_tmp) (void)hipFree(d_tmp);
+        d_tmp = nullptr;
+    };
+#define PREP(call) do { rc = (call); if (rc != LZX_OK) { cleanup(); return rc; } } while (0)
+#define PREP_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); \
+        return e_ == hipErrorOutOfMemory ? LZX_ERR_NOMEM : LZX_ERR_HIP; } } while (0)
+
+    PREP(dev_alloc(&d_deg, n)); PREP(dev_alloc(&d_ids, n));
+    PREP(dev_alloc(&d_sdeg, n)); PREP(dev_alloc(&d_sids, n));
+    PREP(dev_alloc(&d_code, n));
+    PREP(dev_alloc(&c->d_gidx_of_old, n));
+    const u32 gb = (u32)((n + 255) / 256);
+    hipLaunchKernelGGL(k_degrees, dim3(gb), dim3(256), 0, st, c->d_row_ptr, d_deg, d_ids, n);
+    size_t tmp_bytes = 0;
+    PREP_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_deg, d_sdeg, d_ids, d_sids,
+                                                         (u64)n, 0, 32, st));
+    PREP_HIP(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    PREP_HIP(hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tmp_bytes, d_deg, d_sdeg, d_ids, d_sids,
+                                                         (u64)n, 0, 32, st));
+    hipLaunchKernelGGL(k_rank_maps, dim3(gb), dim3(256), 0, st, d_sids, c->d_gidx_of_old, d_code, n,
+                       world, c->n_loc_pad, c->hub);
+    {
+        u32 md = 0;
+        PREP_HIP(hipMemcpyAsync(&md, d_sdeg, sizeof(u32), hipMemcpyDeviceToHost, st));
+        PREP_HIP(hipStreamSynchronize(st));
+        c->max_degree = md;
+    }
+
+    // ---- 2. this rank's rows ----
+    PREP(dev_alloc(&d_old_of_local, c->n_loc_real)); PREP(dev_alloc(&d_deg_local, c->n_loc_real));
+    if (c->n_loc_real) {
+        hipLaunchKernelGGL(k_local_rows, dim3((c->n_loc_real + 255) / 256), dim3(256), 0, st, d_sids, d_sdeg,
+                           d_old_of_local, d_deg_local, c->n_loc_real, world, rank);
+    }
+    degl.assign(c->n_loc_pad, 0);
+    if (c->n_loc_real)
+        PREP_HIP(hipMemcpyAsync(degl.data(), d_deg_local, sizeof(u32) * c->n_loc_real, hipMemcpyDeviceToHost, st));
+    PREP_HIP(hipStreamSynchronize(st));
+
+    // ---- 3. host: split rows / slices (local rows are sorted by degree, descending) ----
+    u32 n_long = 0;
+    c->nnz_local = 0;
+    for (u32 l = 0; l < c->n_loc_real; ++l) {
+        c->nnz_local += degl[l];
+        if (degl[l] > LZX_LONG_ROW) n_long = l + 1;
+    }
+    c->n_long_true = n_long;
+    c->n_long64 = std::min(round_up(n_long, LZX_SLICE), c->n_loc_pad);
+    c->n_slices = (c->n_loc_pad - c->n_long64) / LZX_SLICE;
+
+    h_long_ptr.assign((size_t)c->n_long64 + 1, 0);
+    h_item_first.assign((size_t)c->n_long64 + 1, 0);
+    for (u32 r = 0; r < c->n_long64; ++r) {
+        const u32 dp = round_up(degl[r], 4);
+        h_long_ptr[r + 1] = h_long_ptr[r] + dp;
+        h_item_first[r] = (u32)h_item_beg.size();
+        for (u32 b = 0; b < dp; b += LZX_ITEM) {
+            h_item_beg.push_back(h_long_ptr[r] + b);
+            h_item_len.push_back(std::min(LZX_ITEM, dp - b));
+        }
+    }
+    h_item_first[c->n_long64] = (u32)h_item_beg.size();
+    c->n_items = (u32)h_item_beg.size();
+    c->long_elems = h_long_ptr[c->n_long64];
+
+    h_slice_off.assign(c->n_slices, 0);
+    h_slice_w.assign(c->n_slices, 0);
+    u64 off = 0;
+    for (u32 s = 0; s < c->n_slices; ++s) {
+        const u32 w = round_up(degl[c->n_long64 + s * LZX_SLICE], 4);
+        h_slice_off[s] = off;
+        h_slice_w[s] = w;
+        off += (u64)w * LZX_SLICE;
+    }
+    c->sell_elems = off;
+
+    // ---- 4. upload tables, fill column codes ----
+    PREP(dev_alloc(&c->d_slice_off, c->n_slices)); PREP(dev_alloc(&c->d_slice_w, c->n_slices));
+    PREP(dev_alloc(&c->d_sell_cols, c->sell_elems + 4));
+    PREP(dev_alloc(&c->d_long_cols, c->long_elems + 4));
+    PREP(dev_alloc(&c->d_item_beg, c->n_items)); PREP(dev_alloc(&c->d_item_len, c->n_items));
+    PREP(dev_alloc(&c->d_item_first, (u64)c->n_long64 + 1));
+    PREP(dev_alloc(&c->d_long_partial, c->n_items));
+    PREP(dev_alloc(&d_long_ptr, (u64)c->n_long64 + 1));
+    if (c->n_slices) {
+        PREP_HIP(hipMemcpyAsync(c->d_slice_off, h_slice_off.data(), sizeof(u64) * c->n_slices, hipMemcpyHostToDevice, st));
+        PREP_HIP(hipMemcpyAsync(c->d_slice_w, h_slice_w.data(), sizeof(u32) * c->n_slices, hipMemcpyHostToDevice, st));
+    }
+    if (c->n_items) {
+        PREP_HIP(hipMemcpyAsync(c->d_item_beg, h_item_beg.data(), sizeof(u64) * c->n_items, hipMemcpyHostToDevice, st));
+        PREP_HIP(hipMemcpyAsync(c->d_item_len, h_item_len.data(), sizeof(u32) * c->n_items, hipMemcpyHostToDevice, st));
+    }
+    PREP_HIP(hipMemcpyAsync(c->d_item_first, h_item_first.data(), sizeof(u32) * ((size_t)c->n_long64 + 1), hipMemcpyHostToDevice, st));
+    PREP_HIP(hipMemcpyAsync(d_long_ptr, h_long_ptr.data(), sizeof(u64) * ((size_t)c->n_long64 + 1), hipMemcpyHostToDevice, st));
+    if (c->n_slices) {
+        const u32 rows = c->n_loc_pad - c->n_long64;
+        hipLaunchKernelGGL(k_fill_sell, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx,
+                           d_code, d_old_of_local, d_deg_local, c->n_loc_real, c->n_long64, c->n_loc_pad,
+                           c->d_slice_off, c->d_slice_w, c->d_sell_cols, sentinel);
+    }
+    if (c->n_long64) {
+        hipLaunchKernelGGL(k_fill_long, dim3(c->n_long64), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
+                           d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, c->d_long_cols, sentinel);
+    }
+    PREP_HIP(hipGetLastError());
+
+    // ---- 5. vectors ----
+    PREP(dev_alloc(&c->d_v, c->ldq));
+    PREP(dev_alloc(&c->d_xbuf, c->xlen)); PREP(dev_alloc(&c->d_ybuf, c->xlen));
+    PREP(dev_alloc(&c->d_io, n));
+    PREP_HIP(hipMemsetAsync(c->d_v, 0, sizeof(double) * c->ldq, st));
+    PREP_HIP(hipMemsetAsync(c->d_xbuf, 0, sizeof(double) * c->xlen, st));
+    PREP_HIP(hipMemsetAsync(c->d_ybuf, 0, sizeof(double) * c->xlen, st));
+
+    // launch shape: persistent workgroups, as many as stay resident (LDS-limited), never more than
+    // there is work for.
+    const size_t lds_per_cu = 160 * 1024;
+    u32 per_cu = (u32)std::max<size_t>(1, std::min<size_t>(2, lds_per_cu / std::max<size_t>(c->spmv_lds, 1)));
+    if (c->wgs_per_cu_opt > 0) per_cu = (u32)c->wgs_per_cu_opt;
+    const u32 units = c->n_slices + c->n_items;
+    const u32 waves_per_wg = LZX_SPMV_BLOCK / 64;
+    u32 grid = (u32)c->cu_count * per_cu;
+    grid = std::min(grid, std::max(1u, (units + waves_per_wg - 1) / waves_per_wg));
+    c->spmv_grid = grid;
+    c->fin_grid = (c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
+    c->np_cap = std::max<u32>(c->spmv_grid + c->fin_grid, (u32)c->cu_count * 8) + 8;
+    PREP(dev_alloc(&c->d_partials, c->np_cap)); PREP(dev_alloc(&c->d_partials2, c->np_cap));
+
+    PREP_HIP(hipStreamSynchronize(st));
+    cleanup();
+#undef PREP
+#undef PREP_HIP
+    return LZX_OK;
+}
+
+// --------------------------------------------------------------------------------------------------
+// ingest: sorted unique directed keys (row << 32 | col) -> CSR
+__global__ void k_keys_to_csr(const u64 *keys, u64 nkeys, u64 n, u64 *row_ptr, u32 *col_idx)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nkeys) col_idx[i] = (u32)(keys[i] & 0xffffffffu);
+    if (i <= n) {
+        // first key whose row >= i
+        u64 lo = 0, hi = nkeys;
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if ((keys[mid] >> 32) < i) lo = mid + 1; else hi = mid;
+        }
+        row_ptr[i] = lo;
+    }
+}
+
+// d_keys[nkeys] unsorted, ~0 marks a dropped entry.  Consumes (frees) d_keys.
+static int csr_from_keys_dev(lzx_ctx *c, u64 n, u64 *d_keys, u64 nkeys)
+{
+    hipStream_t st = c->stream;
+    u64 *d_sorted = nullptr, *d_uniq = nullptr, *d_count = nullptr;
+    void *d_tmp = nullptr;
+    int rc = LZX_OK;
+    auto cleanup = [&]() {
+        dev_free(d_keys); dev_free(d_sorted); dev_free(d_uniq); dev_free(d_count);
+        if (d_tmp) (void)hipFree(d_tmp);
+        d_tmp = nullptr;
+    };
+#define ING(call) do { rc = (call); if (rc != LZX_OK) { cleanup(); return rc; } } while (0)
+#define ING_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); \
+        return e_ == hipErrorOutOfMemory ? LZX_ERR_NOMEM : LZX_ERR_HIP; } } while (0)
+    if (nkeys >= (1ull << 31)) { cleanup(); LZX_FAIL(LZX_ERR_LIMIT, "edge list too long for one sort (%llu keys)", (unsigned long long)nkeys); }
+    ING(dev_alloc(&d_sorted, nkeys)); ING(dev_alloc(&d_count, 1));
+    size_t tb = 0;
+    ING_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_keys, d_sorted, (u64)nkeys, 0, 64, st));
+    ING_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
+    ING_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_keys, d_sorted, (u64)nkeys, 0, 64, st));
+    (void)hipFree(d_tmp); d_tmp = nullptr;
+    dev_free(d_keys);
+    ING(dev_alloc(&d_uniq, nkeys));
+    tb = 0;
+    ING_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, d_sorted, d_uniq, d_count, (u64)nkeys, st));
+    ING_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
+    ING_HIP(hipcub::DeviceSelect::Unique(d_tmp, tb, d_sorted, d_uniq, d_count, (u64)nkeys, st));
+    u64 cnt = 0, last = 0;
+    ING_HIP(hipMemcpyAsync(&cnt, d_count, sizeof(u64), hipMemcpyDeviceToHost, st));
+    ING_HIP(hipStreamSynchronize(st));
+    if (cnt > 0) {
+        ING_HIP(hipMemcpyAsync(&last, d_uniq + (cnt - 1), sizeof(u64), hipMemcpyDeviceToHost, st));
+        ING_HIP(hipStreamSynchronize(st));
+        if (last == ~0ull) --cnt;  // the dropped-entry marker sorts last
+    }
+    lzx_graph_release(c);
+    c->n = n;
+    c->nnz = cnt;
+    ING(dev_alloc(&c->d_row_ptr, n + 1)); ING(dev_alloc(&c->d_col_idx, cnt));
+    const u64 work = std::max<u64>(cnt, n + 1);
+    hipLaunchKernelGGL(k_keys_to_csr, dim3((u32)((work + 255) / 256)), dim3(256), 0, st, d_uniq, cnt, n,
+                       c->d_row_ptr, c->d_col_idx);
+    ING_HIP(hipGetLastError());
+    ING_HIP(hipStreamSynchronize(st));
+    cleanup();
+#undef ING
+#undef ING_HIP
+    return lzx_graph_prepare(c);
+}
+
+__global__ void k_edges_to_keys(const u32 *src, const u32 *dst, u64 m, u64 n, u64 *keys)
+{
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const u64 u = src[e], v = dst[e];
+    const bool ok = (u != v) && u < n && v < n;
+    keys[2 * e] = ok ? ((u << 32) | v) : ~0ull;
+    keys[2 * e + 1] = ok ? ((v << 32) | u) : ~0ull;
+}
+
+__device__ __forceinline__ u64 gen_word(u64 seed, u64 ctr)
+{
+    u64 z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// oracle/lanczos_oracle.c: orc_gen_er_keys / orc_gen_rmat_keys, one thread per draw.
+__global__ void k_gen_keys(int kind, u32 scale, u64 n, u64 draws, u64 seed, u32 ta, u32 tab, u32 tabc,
+                           u64 *keys)
+{
+    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= draws) return;
+    u64 u = 0, v = 0;
+    bool ok = false;
+    if (kind == 0) {
+        u = ((gen_word(seed, 2 * e) >> 32) * n) >> 32;
+        v = ((gen_word(seed, 2 * e + 1) >> 32) * n) >> 32;
+        ok = (u != v);
+    } else {
+        for (u32 t = 0; t < 8; ++t) {
+            u64 w = 0;
+            u = 0; v = 0;
+            for (u32 l = 0; l < scale; ++l) {
+                if ((l & 3) == 0) w = gen_word(seed, (e * 8 + t) * 8 + (l >> 2));
+                const u32 r = (u32)(w & 0xffff);
+                w >>= 16;
+                const u32 ub = r >= tab;
+                const u32 vb = (r >= ta && r < tab) || r >= tabc;
+                u = (u << 1) | ub;
+                v = (v << 1) | vb;
+            }
+            if (u < n && v < n) { ok = (u != v); break; }
+        }
+    }
+    keys[2 * e] = ok ? ((u << 32) | v) : ~0ull;
+    keys[2 * e + 1] = ok ? ((v << 32) | u) : ~0ull;
+}
+
+extern "C" int lzx_set_graph_edges(lzx_handle c, uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst)
+{
+    if (!c || (m && (!src || !dst)) || n == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_edges: bad argument");
+    LZX_HIP(hipSetDevice(c->device));
+    u32 *d_src = nullptr, *d_dst = nullptr;
+    u64 *d_keys = nullptr;
+    LZX_TRY(dev_alloc(&d_src, m));
+    if (dev_alloc(&d_dst, m) != LZX_OK) { dev_free(d_src); return LZX_ERR_NOMEM; }
+    if (dev_alloc(&d_keys, 2 * m) != LZX_OK) { dev_free(d_src); dev_free(d_dst); return LZX_ERR_NOMEM; }
+    hipError_t e = hipSuccess;
+    if (m) {
+        e = hipMemcpyAsync(d_src, src, sizeof(u32) * m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst, sizeof(u32) * m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_edges_to_keys, dim3((u32)((m + 255) / 256)), dim3(256), 0, c->stream, d_src, d_dst, m, n, d_keys);
+            e = hipStreamSynchronize(c->stream);
+        }
+    }
+    dev_free(d_src); dev_free(d_dst);
+    if (e != hipSuccess) { dev_free(d_keys); LZX_FAIL(LZX_ERR_HIP, "edge upload: %s", hipGetErrorString(e)); }
+    return csr_from_keys_dev(c, n, d_keys, 2 * m);
+}
+
+extern "C" int lzx_gen_graph(lzx_handle c, int kind, uint32_t scale, uint64_t n, uint64_t draws, uint64_t seed,
+                             uint32_t ta, uint32_t tab, uint32_t tabc)
+{
+    if (!c || n == 0 || (kind != 0 && kind != 1)) LZX_FAIL(LZX_ERR_ARG, "lzx_gen_graph: bad argument");
+    if (kind == 1 && (scale == 0 || scale > 32 || n > (1ull << scale))) LZX_FAIL(LZX_ERR_ARG, "lzx_gen_graph: scale/n mismatch");
+    LZX_HIP(hipSetDevice(c->device));
+    u64 *d_keys = nullptr;
+    LZX_TRY(dev_alloc(&d_keys, 2 * draws));
+    if (draws) {
+        hipLaunchKernelGGL(k_gen_keys, dim3((u32)((draws + 255) / 256)), dim3(256), 0, c->stream, kind, scale, n,
+                           draws, seed, ta, tab, tabc, d_keys);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { dev_free(d_keys); LZX_FAIL(LZX_ERR_HIP, "generator: %s", hipGetErrorString(e)); }
+    }
+    return csr_from_keys_dev(c, n, d_keys, 2 * draws);
+}
+
+static int set_csr_common(lzx_ctx *c, u64 n, u64 nnz, const u64 *row_ptr64, const u32 *row_ptr32, const u32 *col_idx)
+{
+    if (!c || n == 0 || (!row_ptr64 && !row_ptr32) || (nnz && !col_idx)) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: bad argument");
+    LZX_HIP(hipSetDevice(c->device));
+    std::vector<u64> widened;
+    if (!row_ptr64) {
+        widened.resize(n + 1);
+        for (u64 i = 0; i <= n; ++i) widened[i] = row_ptr32[i];
+        row_ptr64 = widened.data();
+    }
+    if (row_ptr64[0] != 0 || row_ptr64[n] != nnz) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: row_ptr[0] must be 0 and row_ptr[n] must equal nnz");
+    lzx_graph_release(c);
+    c->n = n;
+    c->nnz = nnz;
+    LZX_TRY(dev_alloc(&c->d_row_ptr, n + 1));
+    LZX_TRY(dev_alloc(&c->d_col_idx, nnz));
+    LZX_HIP(hipMemcpyAsync(c->d_row_ptr, row_ptr64, sizeof(u64) * (n + 1), hipMemcpyHostToDevice, c->stream));
+    if (nnz) LZX_HIP(hipMemcpyAsync(c->d_col_idx, col_idx, sizeof(u32) * nnz, hipMemcpyHostToDevice, c->stream));
+    LZX_HIP(hipStreamSynchronize(c->stream));
+    return lzx_graph_prepare(c);
+}
+
+extern "C" int lzx_set_graph_csr(lzx_handle c, uint64_t n, uint64_t nnz, const uint64_t *row_ptr, const uint32_t *col_idx)
+{
+    return set_csr_common(c, n, nnz, row_ptr, nullptr, col_idx);
+}
+
+extern "C" int lzx_set_graph_csr32(lzx_handle c, uint32_t n, uint32_t nnz, const uint32_t *row_ptr, const uint32_t *col_idx)
+{
+    return set_csr_common(c, n, nnz, nullptr, row_ptr, col_idx);
+}
+
+extern "C" int lzx_get_graph_csr(lzx_handle c, uint64_t *row_ptr, uint32_t *col_idx)
+{
+    if (!c || !row_ptr || !col_idx) LZX_FAIL(LZX_ERR_ARG, "lzx_get_graph_csr: bad argument");
+    if (!c->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "no graph set");
+    LZX_HIP(hipSetDevice(c->device));
+    LZX_HIP(hipMemcpy(row_ptr, c->d_row_ptr, sizeof(u64) * (c->n + 1), hipMemcpyDeviceToHost));
+    if (c->nnz) LZX_HIP(hipMemcpy(col_idx, c->d_col_idx, sizeof(u32) * c->nnz, hipMemcpyDeviceToHost));
+    return LZX_OK;
+}
+
+extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
+{
+    if (!c || !o) LZX_FAIL(LZX_ERR_ARG, "lzx_get_graph_info: bad argument");
+    if (!c->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "no graph set");
+    o->n = c->n;
+    o->nnz = c->nnz;
+    o->max_degree = c->max_degree;
+    o->rows_local = c->n_loc_real;
+    o->nnz_local = c->nnz_local;
+    o->long_rows = c->n_long_true;
+    o->sell_padded = c->sell_elems + c->long_elems;
+    o->hub_entries = c->hub;
+    o->world = (uint32_t)c->world;
+    o->rank = (uint32_t)c->rank;
+    return LZX_OK;
+}

@@ -1,0 +1,152 @@
+// lzx_internal.h -- shared state of liblzx.so (not part of the public boundary; see include/lzx.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "lzx.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void lzx_set_error(const char *fmt, ...);
+
+#define LZX_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return (e_ == hipErrorOutOfMemory) ? LZX_ERR_NOMEM : LZX_ERR_HIP;                   \
+        }                                                                                      \
+    } while (0)
+
+#define LZX_TRY(call)              \
+    do {                           \
+        int rc_ = (call);          \
+        if (rc_ != LZX_OK) return rc_; \
+    } while (0)
+
+#define LZX_FAIL(code, ...)       \
+    do {                          \
+        lzx_set_error(__VA_ARGS__); \
+        return (code);            \
+    } while (0)
+
+// ---- layout constants -----------------------------------------------------------------------------
+// Sliced-ELL body: slices of 64 rows (one wavefront), column indices stored so that lane l of the
+// wave reads 16 contiguous bytes (4 indices of ITS row) per step and the wave reads 1 KiB contiguous.
+static constexpr u32 LZX_SLICE = 64;
+// Rows with more entries than this leave the sliced-ELL body and are split into wave-sized items.
+static constexpr u32 LZX_LONG_ROW = 1024;
+// Entries one wavefront sums per split-row item (multiple of 256 = 64 lanes x 4 indices).
+static constexpr u32 LZX_ITEM = 2048;
+// Threads per workgroup of the SpMV kernel (16 wavefronts share one LDS copy of the hub entries).
+static constexpr u32 LZX_SPMV_BLOCK = 1024;
+static constexpr u32 LZX_VEC_BLOCK = 256;
+// Zero tail behind every full-length vector: the padding column index points here.
+static constexpr u32 LZX_TAIL = 64;
+
+struct lzx_ctx {
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;       // scratch timing pair
+    hipEvent_t ev_phase = nullptr;                    // cross-handle ordering in local-comm mode
+    std::vector<hipEvent_t> ev_pool;                  // per-iteration timing events
+
+    // ---- communicator ----
+    int world = 1, rank = 0;
+    int comm_kind = 0;                 // 0 none, 1 local (one process, peers[]), 2 RCCL
+    lzx_ctx **peers = nullptr;         // local mode: all handles, index = rank (owned by rank 0's array copy)
+    void *nccl_comm = nullptr;
+
+    // ---- whole graph, caller's vertex order (device) ----
+    u64 n = 0, nnz = 0, max_degree = 0;
+    u64 *d_row_ptr = nullptr;
+    u32 *d_col_idx = nullptr;
+
+    // ---- this rank's share, internal order ----
+    u32 n_loc_real = 0;                // rows owned
+    u32 n_loc_pad = 0;                 // slice stride of the exchanged vector (multiple of 64, same on all ranks)
+    u32 ldq = 0;                       // stride between basis vectors = n_loc_pad + LZX_TAIL
+    u64 xlen = 0;                      // world * n_loc_pad + LZX_TAIL
+    u64 nnz_local = 0;
+    u32 *d_gidx_of_old = nullptr;      // [n] position of caller's vertex o in the full-length layout
+    u32 hub = 0;                       // entries staged in LDS
+    int64_t hub_opt = -1;              // user override (-1: default)
+    int64_t wgs_per_cu_opt = -1;
+    int64_t nt_opt = -1;
+
+    // sliced-ELL body
+    u32 n_long64 = 0;                  // local rows [0, n_long64) go through the split-row path
+    u32 n_long_true = 0;
+    u32 n_slices = 0;
+    u64 sell_elems = 0;
+    u64 *d_slice_off = nullptr;        // [n_slices] element offset of slice s in d_sell_cols
+    u32 *d_slice_w = nullptr;          // [n_slices] width (multiple of 4)
+    u32 *d_sell_cols = nullptr;
+
+    // split rows
+    u32 n_items = 0;
+    u64 long_elems = 0;
+    u32 *d_long_cols = nullptr;
+    u64 *d_item_beg = nullptr;         // [n_items] element offset into d_long_cols
+    u32 *d_item_len = nullptr;         // [n_items] entries (multiple of 4)
+    u32 *d_item_first = nullptr;       // [n_long64 + 1] first item of each split row
+    double *d_long_partial = nullptr;  // [n_items]
+
+    // vectors and scalars
+    double *d_v = nullptr;             // [ldq]
+    double *d_Q = nullptr;             // [q_cols][ldq]
+    u32 q_cols = 0;
+    u32 k_last = 0;                    // valid basis vectors from the last decomposition
+    double *d_xbuf = nullptr;          // [xlen] full-length exchange buffer
+    double *d_ybuf = nullptr;          // [xlen] second full-length buffer (hooks, multout)
+    double *d_io = nullptr;            // [n] staging in the caller's order
+    double *d_partials = nullptr;      // [np_cap] block partials of the running reduction
+    double *d_partials2 = nullptr;     // [np_cap]
+    u32 np_cap = 0;
+    double *d_alpha = nullptr, *d_beta = nullptr;  // [k_cap]
+    u32 k_cap = 0;
+    double *d_scal = nullptr;          // [8 + world] reduced scalars for the exchange path
+
+    // launch shape of the SpMV kernel
+    u32 spmv_grid = 0;
+    u32 fin_grid = 0;
+    size_t spmv_lds = 0;
+};
+
+// ---- lzx_graph.hip ----
+int lzx_graph_release(lzx_ctx *c);
+int lzx_graph_prepare(lzx_ctx *c);   // builds this rank's share from d_row_ptr/d_col_idx
+
+// ---- lzx_kernels.hip ----
+struct SpmvLaunch {
+    const double *x;       // full-length input vector (xlen layout)
+    const double *q_loc;   // this rank's slice of it (for the fused alpha partial)
+    double *v;             // [n_loc_pad] output
+    double *partials;      // block partials of v.q_loc ; count returned by lzx_spmv_partials()
+};
+int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &a);
+u32 lzx_spmv_partials(const lzx_ctx *c);
+int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, int do_sqrt);
+// v -= alpha q_j (+ beta_prev q_jm1); alpha = sum(partials_in); writes alpha_out; partial ||v||^2 out.
+int lzx_launch_axpy_norm(lzx_ctx *c, double *v, const double *qj, const double *qjm1,
+                         const double *partials_in, u32 np_in, double *alpha_out,
+                         const double *beta_prev, double *partials_out, u32 *np_out);
+// q_next = v / sqrt(sum(partials_in)); writes beta_out.  in_is_sqrt: partials_in[0] already holds beta^2 summed.
+int lzx_launch_scale(lzx_ctx *c, const double *v, double *q_next, const double *partials_in,
+                     u32 np_in, double *beta_out);
+int lzx_launch_permute_in(lzx_ctx *c, const double *io_old_order, double *full, double scale);
+int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io_old_order);
+int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc);
+
+// ---- lzx_comm.hip ----
+int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot);        // d_scal[slot] on every handle
+int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full);
+void lzx_comm_release(lzx_ctx *c);

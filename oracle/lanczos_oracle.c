@@ -1,0 +1,214 @@
+/*
+ * oracle/lanczos_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, single-threaded CPU restatement of the reference's Lanczos hot
+ * path (hdelan/MSc-HPC-Final-Project, serial/).  Only tests/, the smoke check
+ * in __graft_entry__.py and bench.py's `cpu_baseline` leg may load this file's
+ * shared object; the product (liblzx.so) never links or calls it.
+ *
+ * Every function cites the reference lines whose arithmetic (operation order
+ * included) it restates.  Build with -O2 -ffp-contract=off so that no FMA is
+ * formed: the reference is built with g++ -O3 for generic x86-64, which has no
+ * FMA either (serial/Makefile:3-6).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - orc_spmv and the text loader (orc_csr_from_keys + oracle.py) are checked
+ *     bit-for-bit against the reference's own SPMV.cc / adjMatrix.cc compiled
+ *     from /root/reference into oracle/_ref/ (tests/test_oracle_ref.py) and
+ *     against golden fixtures made from that build (tests/golden/).
+ *   - orc_lanczos restates serial/lib/lanczos.cc:9-56.  That file includes
+ *     "lapacke.h", which this image does not ship, so it cannot be compiled
+ *     here without stand-in headers; the loop is therefore pinned by running
+ *     it over the *reference's compiled spMV* (same bits as over orc_spmv) and
+ *     by an independent e^A x (scipy expm_multiply) -- "parity unpinned" for
+ *     the loop itself in the strict sense.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* spMV: serial/lib/SPMV.cc:19-28.  out zeroed first, then for every row the
+ * gathered inputs are added one at a time, ascending j, *through memory*
+ * (out[i] += ...), i.e. a strictly sequential left-to-right fp64 sum.        */
+void orc_spmv(uint64_t n, const uint64_t *row_offset, const uint32_t *col_idx,
+              const double *in, double *out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = 0.0;
+    for (uint64_t i = 0; i < n; ++i) {
+        double acc = out[i];
+        for (uint64_t j = row_offset[i]; j < row_offset[i + 1]; ++j)
+            acc += in[col_idx[j]];
+        out[i] = acc;
+    }
+}
+
+/* lanczosDecomp::norm: serial/lib/lanczos.cc:155-161 (left-to-right sum of
+ * squares, then sqrt).                                                       */
+double orc_norm(uint64_t n, const double *v)
+{
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) s += v[i] * v[i];
+    return sqrt(s);
+}
+
+/* lanczosDecomp::inner_prod: serial/lib/lanczos.cc:163-171.                  */
+double orc_inner_prod(uint64_t n, const double *v, const double *w)
+{
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) s += v[i] * w[i];
+    return s;
+}
+
+/* Optional external SpMV (used by tests to run this loop over the reference's
+ * own compiled spMV from oracle/_ref).                                       */
+typedef void (*orc_spmv_fn)(void *user, const double *in, double *out);
+
+/* lanczosDecomp::decompose: serial/lib/lanczos.cc:9-56.
+ *   Q_s[i] = x / ||x||                                            (16-17)
+ *   for j in 0..k-1:
+ *     v = A Q_s[i]                                                (23)
+ *     alpha[j] = <v, Q_s[i]>                                      (26)
+ *     v -= alpha[j] * Q_s[i]                                      (29-30)
+ *     if j > 0:    v -= beta[j-1] * Q_s[1-i]                      (32-37)
+ *     if j < k-1:  beta[j] = ||v||;  Q_s[1-i] = v / beta[j]       (39-44)
+ *     Q[j + row*k] = Q_s[i][row]      (row-major n x k)           (47-48)
+ *     i = 1 - i
+ * Q may be NULL (no basis kept: used by the timed CPU baseline at sizes where
+ * the n*k basis is not wanted).  q_colmajor != 0 stores Q as k contiguous
+ * vectors (the layout parallel-final's GPU path hands to multOut with
+ * Qtrans=true, parallel-final/lib/cu_lanczos.cu:126) instead of row-major.
+ * Returns 0, or -1 on allocation failure.                                    */
+int orc_lanczos(uint64_t n, const uint64_t *row_offset, const uint32_t *col_idx,
+                uint32_t k, const double *x, double *alpha, double *beta,
+                double *Q, int q_colmajor, double *x_norm_out,
+                orc_spmv_fn ext_spmv, void *ext_user)
+{
+    double *v = (double *)malloc(sizeof(double) * n);
+    double *Q_raw = (double *)malloc(sizeof(double) * 2 * n);
+    if (!v || !Q_raw) { free(v); free(Q_raw); return -1; }
+    double *Q_s[2] = { Q_raw, Q_raw + n };
+    unsigned i = 0;
+    const double x_norm = orc_norm(n, x);
+    if (x_norm_out) *x_norm_out = x_norm;
+
+    for (uint64_t r = 0; r < n; ++r) Q_s[i][r] = x[r] / x_norm;
+
+    for (uint32_t j = 0; j < k; ++j) {
+        if (ext_spmv) ext_spmv(ext_user, Q_s[i], v);
+        else          orc_spmv(n, row_offset, col_idx, Q_s[i], v);
+
+        alpha[j] = orc_inner_prod(n, v, Q_s[i]);
+
+        for (uint64_t r = 0; r < n; ++r) v[r] -= alpha[j] * Q_s[i][r];
+
+        if (j > 0)
+            for (uint64_t r = 0; r < n; ++r) v[r] -= beta[j - 1] * Q_s[1 - i][r];
+
+        if (j < k - 1) {
+            beta[j] = orc_norm(n, v);
+            for (uint64_t r = 0; r < n; ++r) Q_s[1 - i][r] = v[r] / beta[j];
+        }
+
+        if (Q) {
+            if (q_colmajor) memcpy(Q + (uint64_t)j * n, Q_s[i], sizeof(double) * n);
+            else for (uint64_t r = 0; r < n; ++r) Q[j + r * (uint64_t)k] = Q_s[i][r];
+        }
+        i = 1 - i;
+    }
+    free(v);
+    free(Q_raw);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CSR from a sorted, de-duplicated list of directed-edge keys
+ * key = (row << 32) | col.  Restates the emission loop of
+ * adjMatrix::populate_sparse_matrix, serial/lib/adjMatrix.cc:34-41, which
+ * walks a std::set<Edge> ordered by (n1, n2) (serial/lib/edge.h:11-14).
+ * Deviation, on purpose: the reference never writes row_offset[0] and never
+ * writes the offsets of empty rows that follow the last non-empty row (it
+ * relies on fresh heap pages being zero / on such rows not existing); here
+ * row_offset[0] = 0 and trailing empty rows get row_offset = nnz, which is
+ * what a well-formed CSR needs and what the reference's own spMV assumes.    */
+void orc_csr_from_keys(uint64_t n, uint64_t nkeys, const uint64_t *keys,
+                       uint64_t *row_offset, uint32_t *col_idx)
+{
+    uint64_t prev_row = 0, i = 0;
+    row_offset[0] = 0;
+    for (; i < nkeys; ++i) {
+        const uint64_t r = keys[i] >> 32;
+        while (prev_row != r) row_offset[++prev_row] = i;
+        col_idx[i] = (uint32_t)(keys[i] & 0xffffffffu);
+    }
+    while (prev_row != n) row_offset[++prev_row] = nkeys;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic graph generators (NOT in the reference: its generators seed from
+ * std::random_device, parallel-final/lib/make_graph.cc:23-24,61-62, so they
+ * cannot be reproduced; SURVEY.md 8(d) asks for seeded counter-based ones).
+ * The random stream is SplitMix64 used as a counter-based generator:
+ *     word(seed, c) = finalise(seed + (c + 1) * 0x9E3779B97F4A7C15)
+ * The HIP generator (csrc/lzx_graph.hip) implements the same integer spec and
+ * tests/ require bit-identical edge lists.                                    */
+static inline uint64_t orc_word(uint64_t seed, uint64_t c)
+{
+    uint64_t z = seed + (c + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* Erdos-Renyi G(n, M draws): draw e uses word 2e -> u, word 2e+1 -> v, each
+ * mapped to [0, n) by the 32x32 multiply-high ((w >> 32) * n) >> 32.
+ * Emits both orientations as keys; self loops are dropped.  Returns the
+ * number of keys written (<= 2 * draws).                                     */
+uint64_t orc_gen_er_keys(uint64_t n, uint64_t draws, uint64_t seed, uint64_t *keys)
+{
+    uint64_t m = 0;
+    for (uint64_t e = 0; e < draws; ++e) {
+        const uint64_t u = ((orc_word(seed, 2 * e) >> 32) * n) >> 32;
+        const uint64_t v = ((orc_word(seed, 2 * e + 1) >> 32) * n) >> 32;
+        if (u == v) continue;
+        keys[m++] = (u << 32) | v;
+        keys[m++] = (v << 32) | u;
+    }
+    return m;
+}
+
+/* R-MAT (Chakrabarti et al.), `scale` levels, quadrant thresholds given as
+ * 16-bit integers: r < ta -> (0,0); r < tab -> (0,1); r < tabc -> (1,0);
+ * else (1,1), r being successive 16-bit fields (low first) of successive
+ * words.  Attempt t of draw e uses words (e * 8 + t) * 8 + w, w < 8
+ * (scale <= 32).  Up to 8 attempts until both endpoints are < n (n need not be
+ * a power of two); a draw whose attempts all fail, or that is a self loop, is
+ * dropped.                                                                    */
+uint64_t orc_gen_rmat_keys(uint32_t scale, uint64_t n, uint64_t draws, uint64_t seed,
+                           uint32_t ta, uint32_t tab, uint32_t tabc, uint64_t *keys)
+{
+    uint64_t m = 0;
+    for (uint64_t e = 0; e < draws; ++e) {
+        for (uint32_t t = 0; t < 8; ++t) {
+            uint64_t u = 0, v = 0, w = 0;
+            for (uint32_t l = 0; l < scale; ++l) {
+                if ((l & 3) == 0) w = orc_word(seed, (e * 8 + t) * 8 + (l >> 2));
+                const uint32_t r = (uint32_t)(w & 0xffff);
+                w >>= 16;
+                const uint32_t ub = r >= tab;                 /* quadrants c, d */
+                const uint32_t vb = (r >= ta && r < tab) || r >= tabc; /* b, d */
+                u = (u << 1) | ub;
+                v = (v << 1) | vb;
+            }
+            if (u < n && v < n) {
+                if (u != v) {
+                    keys[m++] = (u << 32) | v;
+                    keys[m++] = (v << 32) | u;
+                }
+                break;
+            }
+        }
+    }
+    return m;
+}

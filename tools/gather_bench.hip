@@ -1,0 +1,104 @@
+// tools/gather_bench.hip -- microbenchmark behind DESIGN.md's gather-rate table: how many random 8-byte
+// gathers per second does an MI355X sustain when a wave streams 16-byte index packets (as the SpMV does)
+// and the gathered table sits in L2 / Infinity Cache / HBM?  Build: hipcc --offload-arch=gfx950 -O3.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ uint64_t mix(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void fill_idx(uint32_t *idx, uint64_t count, uint32_t table, int skew)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t r = mix((i + 1) * 0x9E3779B97F4A7C15ull);
+    uint32_t v = (uint32_t)(((r >> 32) * table) >> 32);
+    if (skew) {  // R-MAT-like popularity: AND of two uniforms biases towards few set bits
+        uint64_t r2 = mix(r + 12345);
+        v &= (uint32_t)(((r2 >> 32) * table) >> 32) | (uint32_t)(r2 & (r2 >> 13));
+        if (v >= table) v %= table;
+    }
+    idx[i] = v;
+}
+
+template <int UNROLL>
+__global__ void __launch_bounds__(1024) gather_k(const uint32_t *idx, uint64_t packets, const double *tab, double *out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    const uint4 *p = reinterpret_cast<const uint4 *>(idx);
+    double acc = 0.0;
+    uint64_t q = tid;
+    for (; q + (UNROLL - 1) * nthreads < packets; q += UNROLL * nthreads) {
+        uint4 c[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) c[u] = p[q + u * nthreads];
+        double x[UNROLL * 4];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            x[4 * u + 0] = tab[c[u].x]; x[4 * u + 1] = tab[c[u].y];
+            x[4 * u + 2] = tab[c[u].z]; x[4 * u + 3] = tab[c[u].w];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL * 4; ++u) acc += x[u];
+    }
+    if (acc == 1.2345e-300) out[tid] = acc;  // keep the loads alive
+}
+
+__global__ void stream_k(const uint4 *p, uint64_t packets, uint32_t *out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (uint64_t q = tid; q < packets; q += nthreads) { uint4 c = p[q]; acc += c.x ^ c.y ^ c.z ^ c.w; }
+    if (acc == 0x12345678u) out[tid] = acc;
+}
+
+int main(int argc, char **argv)
+{
+    const uint64_t count = 256ull << 20;  // 256 Mi indices = 1 GiB of index stream
+    uint32_t *idx; double *tab, *out;
+    CHECK(hipMalloc(&idx, count * 4));
+    CHECK(hipMalloc(&out, 8ull << 20));
+    const uint64_t max_tab = 256ull << 20;  // doubles (2 GiB)
+    CHECK(hipMalloc(&tab, max_tab * 8));
+    CHECK(hipMemset(tab, 0, max_tab * 8));
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    const int grid = 256 * 2;
+
+    {   // pure index stream
+        float best = 1e30f;
+        for (int r = 0; r < 5; ++r) {
+            CHECK(hipEventRecord(a)); stream_k<<<grid * 4, 256>>>((const uint4 *)idx, count / 4, (uint32_t *)out);
+            CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+            float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+        }
+        printf("index stream only: %.3f ms  %.2f TB/s\n", best, count * 4 / best / 1e9);
+    }
+    const uint64_t tables[] = {4096, 1ull << 17, 1ull << 19, 1ull << 20, 1ull << 22, 10ull << 20, 1ull << 25, 1ull << 27, 1ull << 28};
+    for (int skew = 0; skew < 2; ++skew)
+        for (uint64_t t : tables) {
+            fill_idx<<<(unsigned)((count + 255) / 256), 256>>>(idx, count, (uint32_t)t, skew);
+            CHECK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int r = 0; r < 4; ++r) {
+                CHECK(hipEventRecord(a)); gather_k<2><<<grid, 1024>>>(idx, count / 4, tab, out);
+                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+            }
+            printf("skew=%d table %9.2f MB: %8.3f ms  %7.1f Ggather/s  (index stream %.2f TB/s)\n", skew, t * 8 / 1e6,
+                   best, count / best / 1e6, count * 4 / best / 1e9);
+            fflush(stdout);
+        }
+    return 0;
+}

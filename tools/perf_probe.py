@@ -1,0 +1,39 @@
+"""tools/perf_probe.py -- A/B probe of the SpMV kernel's knobs on synthetic R-MAT graphs (GPU box only).
+usage: python tools/perf_probe.py [c2|c3] ..."""
+import sys
+import time
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as ge
+
+pkg = ge.load_pkg()
+WORK = {"c2": (20, 1 << 20, 20_000_000), "c3": (24, 10_000_000, 200_000_000), "c2b": (20, 1_000_000, 20_000_000)}
+
+
+def run(name, opts_list, k=20):
+    scale, n, draws = WORK[name]
+    for opts in opts_list:
+        eng = pkg.Engine(0, **opts)
+        t = time.time()
+        eng.gen_rmat(scale, n, draws, 1234)
+        tg = time.time() - t
+        gi = eng.info()
+        avg, mn = eng.bench_spmv(20)
+        bytes_ = 4 * gi["nnz"] + 4 * (n + 1) + 8 * n + 8 * n
+        a, b, _, xn, st = eng.lanczos(np.ones(n), k, want_q=False)
+        print(f"{name} {opts} gen={tg:.1f}s n={n} nnz={gi['nnz']} maxdeg={gi['max_degree']} long={gi['long_rows']} "
+              f"padded={gi['sell_padded']} hub={gi['hub_entries']} | spmv avg {avg:.4f} ms min {mn:.4f} ms -> "
+              f"{bytes_ / mn / 1e9:.1f} GB/s ({bytes_ / mn / 1e9 / 8000 * 100:.1f}% of 8 TB/s) | "
+              f"lanczos k={k}: loop {st['loop_ms']:.2f} ms, spmv {st['spmv_ms']:.2f}, vec {st['vec_ms']:.2f} -> "
+              f"{k / st['loop_ms'] * 1e3:.1f} it/s", flush=True)
+        eng.close()
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ["c2"]
+    opts = [dict(), dict(hub_entries=0), dict(hub_entries=16384, wgs_per_cu=1), dict(hub_entries=4096),
+            dict(nt_index_loads=1), dict(hub_entries=0, nt_index_loads=1), dict(wgs_per_cu=1), dict(hub_entries=0, wgs_per_cu=4)]
+    for nm in names:
+        run(nm, opts)
