@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- Lanczos iterations/sec + SpMV effective HBM GB/s on synthetic R-MAT graphs (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1]
+
+A "step" is one Lanczos iteration (serial/lib/lanczos.cc:21-53) on a graph already reshaped and resident in
+HBM; the timed region is exactly K iterations (lzx_lanczos_run), bracketed by a barrier and a device
+synchronisation on both sides, MAX over ranks.  N > 1: one process per GPU (torch.distributed.run), rows
+dealt to ranks by degree rank, the new Lanczos vector re-assembled each iteration by an RCCL all-gather
+inside liblzx.so (torch.distributed only carries the 128-byte communicator id, the barrier and the max).
+The same graph is used at every N, so scaling is "strong".
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+# name -> (description, generator kind, scale, n, draws, seed, default k)
+WORKLOADS = {
+    "c1": ("C1: Erdos-Renyi n=10k, 100k draws, seed 1234", "er", 0, 10_000, 100_000, 1234, 20),
+    "c2": ("C2: R-MAT scale 20 (a,b,c,d)=(.57,.19,.19,.05), n=1,048,576, 20M draws, seed 1234", "rmat", 20,
+           1 << 20, 20_000_000, 1234, 50),
+    "c3": ("C3/C4: R-MAT scale 24 (a,b,c,d)=(.57,.19,.19,.05), endpoints >= n re-drawn, n=10,000,000, "
+           "200M draws, seed 1234", "rmat", 24, 10_000_000, 200_000_000, 1234, 50),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X datasheet, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(eng, O, budget_s: float = 20.0):
+    """The oracle's restatement of serial/ (single thread) on the SAME graph, a bounded number of iterations."""
+    rp, ci = eng.get_graph_csr()
+    n = len(rp) - 1
+    x0 = np.ones(n)
+    t = time.perf_counter()
+    O.lanczos(rp, ci, 2, x0, want_q=False)
+    per_iter = max((time.perf_counter() - t) / 2.0, 1e-6)
+    k = int(max(2, min(50, budget_s / per_iter)))
+    t = time.perf_counter()
+    O.lanczos(rp, ci, k, x0, want_q=False)
+    dt = time.perf_counter() - t
+    return {"value": k / dt, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": f"{k} Lanczos iterations of the same graph (oracle/lanczos_oracle.c, -O2, 1 thread, "
+                      f"{dt:.1f} s; host has {os.cpu_count()} hardware threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("LZX_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch  # device plumbing + torch.distributed only
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_pkg()
+    desc, kind, scale, n, draws, seed, _ = WORKLOADS[args.workload]
+    K, W = args.steps, args.warmup
+
+    eng = pkg.Engine(local_rank)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.from_numpy(pkg.Engine.unique_id()))
+        dist.broadcast(uid, 0)
+        eng.comm_init_rank(uid.cpu().numpy(), rank, world)
+
+    t_gen = time.perf_counter()
+    if kind == "er":
+        eng.gen_er(n, draws, seed)
+    else:
+        eng.gen_rmat(scale, n, draws, seed)
+    t_gen = time.perf_counter() - t_gen
+    gi = eng.info()
+
+    def barrier():
+        eng.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    x0 = np.ones(n)
+    if W > 0:
+        eng.lanczos_prepare(x0, W)
+        eng.lanczos_run()
+    eng.lanczos_prepare(x0, K)   # x0 uploaded, q_0 in HBM: inputs resident before the clock starts
+    barrier()
+    t0 = time.perf_counter()
+    st = eng.lanczos_run()       # exactly K iterations; returns after a stream synchronise
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        agg = torch.tensor([st["spmv_ms"], float(st["spmv_bytes"]), st["comm_ms"], st["vec_ms"]],
+                           dtype=torch.float64, device="cuda")
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        spmv_ms_max, comm_ms, vec_ms = float(mx[0]), float(mx[2]), float(mx[3])
+        spmv_bytes_total = float(agg[1])
+    else:
+        spmv_ms_max, comm_ms, vec_ms = st["spmv_ms"], st["comm_ms"], st["vec_ms"]
+        spmv_bytes_total = float(st["spmv_bytes"])
+
+    alpha, beta, _ = eng.lanczos_fetch(K)
+    finite = bool(np.isfinite(alpha).all() and np.isfinite(beta).all())
+
+    if rank == 0:
+        spmv_avg_ms = spmv_ms_max / K
+        achieved = spmv_bytes_total / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+        out = {
+            "metric": "lanczos_iterations_per_sec",
+            "value": K / elapsed,
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": desc,
+                "n": gi["n"], "undirected_edges": gi["nnz"] // 2, "nnz": gi["nnz"], "max_degree": gi["max_degree"],
+                "k": K, "x0": "ones",
+                "partition": "single GPU" if world == 1 else
+                             f"rows dealt round-robin by degree rank over {world} GPUs; per iteration 1 RCCL "
+                             f"all-gather of {8 * gi['n'] // world} B per rank + 2 one-double all-reduces",
+                "graph_build_s": round(t_gen, 3),
+                "lanczos_coefficients_finite": finite,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_spmv (+ k_long_finish): CSR SpMV fused with the alpha partial",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS * world,
+                "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK_GBS * world),
+                "traffic": None,
+                "algorithmic_bytes_per_spmv": spmv_bytes_total,
+                "avg_spmv_ms": spmv_avg_ms,
+                "spmv_share_of_loop": spmv_ms_max / (elapsed * 1e3),
+                "vector_kernels_ms_per_iter": vec_ms / K,
+                "exchange_ms_per_iter": comm_ms / K,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eng, ge.load_oracle())
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,15 @@ int lzx_spmv_f64_local(lzx_handle *hs, int world, const double *x, double *y);
  * With a communicator every rank must call it with the same arguments.                           */
 int lzx_lanczos_f64(lzx_handle h, const double *x0, uint32_t k, double *alpha, double *beta,
                     double *Q, double *x_norm, lzx_stats *stats);
+/* lzx_lanczos_f64 in three steps, so that a caller can bracket exactly the loop (inputs already in HBM):
+ *   prepare: upload x0, q_0 = x0/||x0||, size the resident basis      (cu_lanczos.cu:30-34,88-94)
+ *   run    : the k iterations, stream-synchronised on return           (cu_lanczos.cu:97-128)
+ *   fetch  : alpha[k], beta[k-1], optionally Q[k*n]                     (cu_lanczos.cu:126,129-130)   */
+int lzx_lanczos_prepare_f64(lzx_handle h, const double *x0, uint32_t k, double *x_norm);
+int lzx_lanczos_run(lzx_handle h, lzx_stats *stats);
+int lzx_lanczos_fetch_f64(lzx_handle h, uint32_t k, double *alpha, double *beta, double *Q);
+/* Wait for everything queued on the handle's stream. */
+int lzx_sync(lzx_handle h);
 /* The same over `world` handles wired with lzx_comm_init_local, driven by one host thread. */
 int lzx_lanczos_f64_local(lzx_handle *hs, int world, const double *x0, uint32_t k, double *alpha,
                           double *beta, double *Q, double *x_norm, lzx_stats *stats);

@@ -63,6 +63,10 @@ SYMBOLS = [
                                        ctypes.POINTER(LzxStats)]),
     ("lzx_lanczos_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p, _f64p, _f64p,
                                              _f64p, ctypes.POINTER(LzxStats)]),
+    ("lzx_lanczos_prepare_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
+    ("lzx_lanczos_run", ctypes.c_int, [_h, ctypes.POINTER(LzxStats)]),
+    ("lzx_lanczos_fetch_f64", ctypes.c_int, [_h, ctypes.c_uint32, _f64p, _f64p, _f64p]),
+    ("lzx_sync", ctypes.c_int, [_h]),
     ("lzx_multout_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
     ("lzx_multout_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p]),
     ("lzx_bench_spmv", ctypes.c_int, [_h, ctypes.c_uint32, _f64p, _f64p]),
@@ -207,6 +211,29 @@ class Engine:
                                      _p(Q, _f64p) if want_q else None, ctypes.byref(xn), ctypes.byref(st)),
                "lzx_lanczos_f64")
         return alpha, beta[:k - 1], Q, xn.value, st.as_dict()
+
+    def lanczos_prepare(self, x0, k: int) -> float:
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        assert len(x0) == self.n
+        xn = ctypes.c_double()
+        _check(lib().lzx_lanczos_prepare_f64(self.h, _p(x0, _f64p), k, ctypes.byref(xn)), "lzx_lanczos_prepare_f64")
+        return xn.value
+
+    def lanczos_run(self) -> dict:
+        st = LzxStats()
+        _check(lib().lzx_lanczos_run(self.h, ctypes.byref(st)), "lzx_lanczos_run")
+        return st.as_dict()
+
+    def lanczos_fetch(self, k: int, want_q: bool = False):
+        alpha = np.zeros(k)
+        beta = np.zeros(max(k - 1, 1))
+        Q = np.empty((k, self.n)) if want_q else None
+        _check(lib().lzx_lanczos_fetch_f64(self.h, k, _p(alpha, _f64p), _p(beta, _f64p),
+                                           _p(Q, _f64p) if want_q else None), "lzx_lanczos_fetch_f64")
+        return alpha, beta[:k - 1], Q
+
+    def sync(self):
+        _check(lib().lzx_sync(self.h), "lzx_sync")
 
     def multout(self, t):
         t = np.ascontiguousarray(t, dtype=np.float64)

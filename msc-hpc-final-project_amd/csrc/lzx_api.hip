@@ -80,6 +80,8 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     if (!strcmp(name, "hub_entries")) c->hub_opt = value;
     else if (!strcmp(name, "wgs_per_cu")) c->wgs_per_cu_opt = value;
     else if (!strcmp(name, "nt_index_loads")) c->nt_opt = value;
+    else if (!strcmp(name, "long_row")) c->long_row_opt = value;
+    else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
 }
@@ -174,10 +176,10 @@ static u64 spmv_algorithmic_bytes(const lzx_ctx *c)
     return 4ull * c->nnz_local + 4ull * ((u64)c->n_loc_real + 1) + 8ull * c->n + 8ull * c->n_loc_real;
 }
 
-static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, double *alpha, double *beta,
-                       double *Q, double *x_norm_out, lzx_stats *stats)
+// Upload x0, normalise it into q_0 and size the resident basis for k vectors.
+static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, double *x_norm_out)
 {
-    if (!x0 || !alpha || k == 0 || (k > 1 && !beta)) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_f64: bad argument");
+    if (!x0 || k == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos: bad argument");
     LZX_TRY(check_graphs(cs));
     lzx_ctx *c0 = cs[0];
     const u64 n = c0->n;
@@ -204,6 +206,21 @@ static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, doub
                                    sizeof(double) * c->n_loc_pad, hipMemcpyDeviceToDevice, c->stream));
         }
     }
+    LZX_TRY(sync_all(cs));
+    for (lzx_ctx *c : cs) c->k_prep = k;
+    return LZX_OK;
+}
+
+// The k-iteration loop proper, on the vectors lanczos_prepare left in HBM.
+static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
+{
+    LZX_TRY(check_graphs(cs));
+    lzx_ctx *c0 = cs[0];
+    const u32 k = c0->k_prep;
+    for (lzx_ctx *c : cs)
+        if (c->k_prep == 0 || c->k_prep != k) LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_run: no prepared start vector");
+    const int world = c0->world;
+    const bool multi = world > 1;
     LZX_TRY(sync_all(cs));
 
     Marks mk{c0};
@@ -284,12 +301,7 @@ static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, doub
     }
     LZX_TRY(sync_all(cs));
     const auto t1 = std::chrono::steady_clock::now();
-    for (lzx_ctx *c : cs) c->k_last = k;
-
-    // ---- outputs ----
-    LZX_HIP(hipSetDevice(c0->device));
-    LZX_HIP(hipMemcpy(alpha, c0->d_alpha, sizeof(double) * k, hipMemcpyDeviceToHost));
-    if (k > 1) LZX_HIP(hipMemcpy(beta, c0->d_beta, sizeof(double) * (k - 1), hipMemcpyDeviceToHost));
+    for (lzx_ctx *c : cs) { c->k_last = k; c->k_prep = 0; }
 
     if (stats) {
         memset(stats, 0, sizeof *stats);
@@ -310,6 +322,23 @@ static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, doub
         }
         if (stats->spmv_ms_min == 1e300) stats->spmv_ms_min = 0.0;
     }
+    return LZX_OK;
+}
+
+// Download alpha, beta and (optionally) the basis in the caller's vertex order.
+static int lanczos_fetch(std::vector<lzx_ctx *> &cs, u32 k, double *alpha, double *beta, double *Q)
+{
+    if (!alpha || k == 0 || (k > 1 && !beta)) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_fetch: bad argument");
+    LZX_TRY(check_graphs(cs));
+    lzx_ctx *c0 = cs[0];
+    if (c0->k_last < k) LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_fetch: only %u iterations are resident", c0->k_last);
+    const u64 n = c0->n;
+    const bool multi = c0->world > 1;
+    std::vector<const double *> src(cs.size());
+    std::vector<double *> dst(cs.size());
+    LZX_HIP(hipSetDevice(c0->device));
+    LZX_HIP(hipMemcpy(alpha, c0->d_alpha, sizeof(double) * k, hipMemcpyDeviceToHost));
+    if (k > 1) LZX_HIP(hipMemcpy(beta, c0->d_beta, sizeof(double) * (k - 1), hipMemcpyDeviceToHost));
 
     if (Q) {
         // k contiguous vectors in the caller's vertex order (cu_lanczos.cu:126 layout)
@@ -330,12 +359,50 @@ static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, doub
     return LZX_OK;
 }
 
+static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, double *alpha, double *beta,
+                       double *Q, double *x_norm_out, lzx_stats *stats)
+{
+    if (!x0 || !alpha || k == 0 || (k > 1 && !beta)) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_f64: bad argument");
+    LZX_TRY(lanczos_prepare(cs, x0, k, x_norm_out));
+    LZX_TRY(lanczos_loop(cs, stats));
+    return lanczos_fetch(cs, k, alpha, beta, Q);
+}
+
 extern "C" int lzx_lanczos_f64(lzx_handle h, const double *x0, uint32_t k, double *alpha, double *beta,
                                double *Q, double *x_norm, lzx_stats *stats)
 {
     std::vector<lzx_ctx *> cs;
     LZX_TRY(gather_handles(h, cs));
     return lanczos_run(cs, x0, k, alpha, beta, Q, x_norm, stats);
+}
+
+extern "C" int lzx_lanczos_prepare_f64(lzx_handle h, const double *x0, uint32_t k, double *x_norm)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    return lanczos_prepare(cs, x0, k, x_norm);
+}
+
+extern "C" int lzx_lanczos_run(lzx_handle h, lzx_stats *stats)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    return lanczos_loop(cs, stats);
+}
+
+extern "C" int lzx_lanczos_fetch_f64(lzx_handle h, uint32_t k, double *alpha, double *beta, double *Q)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    return lanczos_fetch(cs, k, alpha, beta, Q);
+}
+
+extern "C" int lzx_sync(lzx_handle h)
+{
+    if (!h) LZX_FAIL(LZX_ERR_ARG, "lzx_sync: null handle");
+    LZX_HIP(hipSetDevice(h->device));
+    LZX_HIP(hipStreamSynchronize(h->stream));
+    return LZX_OK;
 }
 
 extern "C" int lzx_lanczos_f64_local(lzx_handle *hs, int world, const double *x0, uint32_t k, double *alpha,

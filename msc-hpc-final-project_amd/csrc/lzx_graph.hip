@@ -221,11 +221,12 @@ int lzx_graph_prepare(lzx_ctx *c)
     PREP_HIP(hipStreamSynchronize(st));
 
     // ---- 3. host: split rows / slices (local rows are sorted by degree, descending) ----
+    const u32 long_thr = c->long_row_opt > 0 ? (u32)c->long_row_opt : LZX_LONG_ROW;
     u32 n_long = 0;
     c->nnz_local = 0;
     for (u32 l = 0; l < c->n_loc_real; ++l) {
         c->nnz_local += degl[l];
-        if (degl[l] > LZX_LONG_ROW) n_long = l + 1;
+        if (degl[l] > long_thr) n_long = l + 1;
     }
     c->n_long_true = n_long;
     c->n_long64 = std::min(round_up(n_long, LZX_SLICE), c->n_loc_pad);

@@ -81,6 +81,8 @@ struct lzx_ctx {
     int64_t hub_opt = -1;              // user override (-1: default)
     int64_t wgs_per_cu_opt = -1;
     int64_t nt_opt = -1;
+    int64_t long_row_opt = -1;         // split-row threshold override
+    int64_t phase_mask_opt = 3;        // debug: 1 = split rows only, 2 = body only
 
     // sliced-ELL body
     u32 n_long64 = 0;                  // local rows [0, n_long64) go through the split-row path
@@ -105,6 +107,7 @@ struct lzx_ctx {
     double *d_Q = nullptr;             // [q_cols][ldq]
     u32 q_cols = 0;
     u32 k_last = 0;                    // valid basis vectors from the last decomposition
+    u32 k_prep = 0;                    // iterations a prepared (not yet run) decomposition will take
     double *d_xbuf = nullptr;          // [xlen] full-length exchange buffer
     double *d_ybuf = nullptr;          // [xlen] second full-length buffer (hooks, multout)
     double *d_io = nullptr;            // [n] staging in the caller's order

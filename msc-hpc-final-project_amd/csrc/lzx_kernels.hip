@@ -301,12 +301,12 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.sell_cols = c->d_sell_cols;
     a.slice_off = c->d_slice_off;
     a.slice_w = c->d_slice_w;
-    a.n_slices = c->n_slices;
+    a.n_slices = (c->phase_mask_opt & 2) ? c->n_slices : 0;
     a.row0 = c->n_long64;
     a.long_cols = c->d_long_cols;
     a.item_beg = c->d_item_beg;
     a.item_len = c->d_item_len;
-    a.n_items = c->n_items;
+    a.n_items = (c->phase_mask_opt & 1) ? c->n_items : 0;
     a.long_partial = c->d_long_partial;
     a.x = l.x;
     a.q_loc = l.q_loc;

@@ -1,0 +1,91 @@
+// cu_lanczos.h -- `lanczosDecomp<T>`: the k-step Lanczos decomposition A ~ Q T Q^T, on the CPU
+// (cuda == false) or on an MI355X through the lzx C ABI (cuda == true).
+//
+// Drop-in for parallel-final/lib/cu_lanczos.h:30-108 (file name kept so that `#include "cu_lanczos.h"`
+// keeps working): same constructor -- all work happens in it --, same members alpha / beta / Q / x / ans /
+// x_norm, same friends.  Layout contract kept from the reference:
+//   cuda == false : Q is row-major n x k            (Q[j + row * k], parallel-final/lib/lanczos.cu:54)
+//   cuda == true  : Q is k contiguous vectors of n  (&Q[k * n],      parallel-final/lib/cu_lanczos.cu:126)
+// and multOut's `Qtrans` flag says which one it is given.
+// Not reproduced: the destructor / free_mem defects (cudaFree of a host pointer, leak of Q_d:
+// cu_lanczos.h:75,84) and the silent half-built object after a failed allocation
+// (cu_lanczos.cu:38-72) -- a failed device path throws std::runtime_error with the lzx error text.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+
+#include "adjMatrix.h"
+
+struct lzx_ctx;
+
+template <typename T, typename U>
+T norm(const T *v, U n) {
+  T s = 0;
+  for (U i = 0; i < n; ++i) s += v[i] * v[i];
+  return std::sqrt(s);
+}
+
+template <typename T, typename U>
+T inner_prod(const T *const v, const T *const w, const U n) {
+  T s = 0;
+  for (U i = 0; i < n; ++i) s += v[i] * w[i];
+  return s;
+}
+
+template <typename T> class eigenDecomp;
+template <typename T> class lanczosDecomp;
+template <typename U, typename V> void check_ans(lanczosDecomp<U> &, lanczosDecomp<V> &);
+
+// Timings of the device path of the last constructed decomposition (milliseconds).
+struct lanczosTimings {
+  double loop_ms = 0, spmv_ms = 0, vec_ms = 0, setup_ms = 0;
+  std::uint64_t spmv_bytes = 0;
+};
+
+template <typename T>
+class lanczosDecomp {
+ public:
+  lanczosDecomp() = delete;
+  lanczosDecomp(adjMatrix &adj, const unsigned krylov, T *starting_vec, bool cuda);
+  lanczosDecomp(lanczosDecomp &) = delete;
+  lanczosDecomp &operator=(lanczosDecomp &) = delete;
+  ~lanczosDecomp();
+
+  // Releases the big host arrays early (main.cu:106 does this before the device run to stay out of swap).
+  void free_mem();
+
+  void get_ans() const;
+  unsigned get_n() const { return A.get_n(); }
+  unsigned get_krylov() const { return krylov_dim; }
+  void check_ans(const T *analytic_ans) const;
+  const lanczosTimings &timings() const { return times; }
+  // Extensions over the reference's surface: read access to the results, and whether the basis is
+  // still resident on the GPU (true after a device decomposition until free_mem()).
+  const T *answer() const { return ans; }
+  const T *get_alpha() const { return alpha; }
+  const T *get_beta() const { return beta; }
+  bool on_device() const { return engine != nullptr; }
+
+  friend class eigenDecomp<T>;
+  template <typename U> friend void multOut(lanczosDecomp<U> &, eigenDecomp<U> &, adjMatrix &, bool);
+  template <typename U> friend void cu_multOut(lanczosDecomp<U> &, eigenDecomp<U> &, adjMatrix &, bool);
+  template <typename U, typename V> friend void check_ans(lanczosDecomp<U> &, lanczosDecomp<V> &);
+  template <typename U> friend void write_ans(std::string filename, lanczosDecomp<U> &);
+
+ private:
+  adjMatrix &A;
+  unsigned krylov_dim;
+  T *alpha = nullptr;  // diagonal of T            [k]
+  T *beta = nullptr;   // sub-diagonal of T        [k - 1]
+  T *Q = nullptr;      // Lanczos basis            [n * k], layout above
+  T *x = nullptr;      // starting vector          [n]
+  T *ans = nullptr;    // e^A x once multOut ran   [n]
+  T x_norm;
+  lzx_ctx *engine = nullptr;  // lzx handle of the device path (owns the resident basis)
+  lanczosTimings times;
+
+  void decompose();     // CPU:    serial/lib/lanczos.cc:9-56 == parallel-final/lib/lanczos.cu:17-60
+  void cu_decompose();  // MI355X: replaces parallel-final/lib/cu_lanczos.cu:20-142
+};

@@ -1,0 +1,106 @@
+// host_capi.cc -- a few extern "C" hooks over the C++ drop-in classes so that the test-suite can drive
+// them through ctypes (a C++ caller uses the classes directly; `final` is the command-line face).
+#include <algorithm>
+#include <cstring>
+#include <exception>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "adjMatrix.h"
+#include "cu_lanczos.h"
+#include "eigen.h"
+#include "multiplyOut.h"
+
+static std::string g_host_err;
+
+extern "C" {
+
+const char *host_last_error() { return g_host_err.c_str(); }
+
+// tridiagonal eigen-solver: d[k] in/out, e[k-1] in, z[k*k] out; returns 0 on success
+int host_symtridiag(int k, double *d, const double *e, double *z) {
+  std::vector<double> ec(e, e + (k > 1 ? k - 1 : 0));
+  ec.push_back(0.0);
+  return symtridiag_ql(k, d, ec.data(), z);
+}
+
+// The pipeline of main.cc on a graph file: adjMatrix(N, E, ifstream&) -> lanczosDecomp(cuda) ->
+// eigenDecomp -> multOut / cu_multOut.  Outputs: ans[n], alpha[k], beta[k-1].  Returns n, or < 0.
+long host_expm_file(const char *path, unsigned k, int cuda, int device_multout, double *ans, unsigned ans_len,
+                    double *alpha, double *beta) {
+  try {
+    std::ifstream fs(path);
+    if (fs.fail()) { g_host_err = std::string("cannot open ") + path; return -1; }
+    unsigned n = 0, edges = 0;
+    fs >> n >> n >> edges;
+    adjMatrix A(n, edges, fs);
+    if (ans_len < n) { g_host_err = "answer buffer too small"; return -2; }
+    std::vector<double> x(n, 1.0);
+    lanczosDecomp<double> L(A, k, x.data(), cuda != 0);
+    if (alpha) std::copy(L.get_alpha(), L.get_alpha() + k, alpha);
+    if (beta && k > 1) std::copy(L.get_beta(), L.get_beta() + (k - 1), beta);
+    eigenDecomp<double> E(L);
+    if (cuda && device_multout) cu_multOut(L, E, A, true);
+    else multOut(L, E, A, cuda != 0);
+    std::copy(L.answer(), L.answer() + n, ans);
+    return static_cast<long>(n);
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
+static long dump_csr(const adjMatrix &A, unsigned *row_offset, unsigned *col_idx, unsigned max_nnz) {
+  // the arrays are private (friends only); operator<< prints them in full: "JA" cols, "IA" offsets
+  std::ostringstream os;
+  os << A;
+  std::istringstream is(os.str());
+  std::string tag;
+  is >> tag;
+  const unsigned nnz = 2 * A.get_edges();
+  if (nnz > max_nnz) { g_host_err = "col_idx buffer too small"; return -2; }
+  for (unsigned i = 0; i < nnz; ++i) is >> col_idx[i];
+  is >> tag;
+  for (unsigned i = 0; i <= A.get_n(); ++i) is >> row_offset[i];
+  return static_cast<long>(A.get_edges());
+}
+
+// Seeded generators of the adjMatrix drop-in: kind 'r' G(n, E), 'b' Barabasi (m = E), 'm' R-MAT (scale, draws = E).
+long host_gen_csr(char kind, unsigned scale, unsigned n, unsigned long long E, unsigned long long seed,
+                  unsigned *row_offset, unsigned *col_idx, unsigned max_nnz) {
+  try {
+    if (kind == 'm') return dump_csr(adjMatrix::rmat(scale, n, E, seed), row_offset, col_idx, max_nnz);
+    if (kind == 'r') {
+      adjMatrix A;  // default seed 1234 is what the (N, E) constructor uses
+      (void)seed;
+      A = adjMatrix(n, static_cast<unsigned>(E));
+      return dump_csr(A, row_offset, col_idx, max_nnz);
+    }
+    if (kind == 'b') return dump_csr(adjMatrix(n, static_cast<unsigned>(E), 'b'), row_offset, col_idx, max_nnz);
+    g_host_err = "unknown generator";
+    return -1;
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
+// Loader only: CSR of a graph file as the adjMatrix file constructor builds it.
+// row_offset[n+1], col_idx[2*E] (caller sizes them from the header); returns stored edges or < 0.
+long host_load_csr(const char *path, unsigned *row_offset, unsigned *col_idx, unsigned max_nnz) {
+  try {
+    std::ifstream fs(path);
+    if (fs.fail()) { g_host_err = std::string("cannot open ") + path; return -1; }
+    unsigned n = 0, edges = 0;
+    fs >> n >> n >> edges;
+    adjMatrix A(n, edges, fs);
+    return dump_csr(A, row_offset, col_idx, max_nnz);
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+#include "multiplyOut.h"
+
+#include <cmath>
+#include <stdexcept>
+#include <vector>
+
+#include "lzx.h"
+
+namespace {
+// t = V (e^lambda .* ||x|| V[0,:])  -- multiplyOut.cu:30-40 of the reference: exponentiate the Ritz
+// values in place, weight by the first eigenvector components, one k x k GEMV.
+template <typename T>
+std::vector<T> small_part(T *lambda, const T *V, unsigned k, T x_norm) {
+  for (unsigned j = 0; j < k; ++j) lambda[j] = std::exp(lambda[j]);
+  for (unsigned j = 0; j < k; ++j) lambda[j] *= x_norm * V[j];
+  std::vector<T> t(k);
+  for (unsigned i = 0; i < k; ++i) {
+    T s = 0;
+    for (unsigned j = 0; j < k; ++j) s += V[static_cast<std::size_t>(i) * k + j] * lambda[j];
+    t[i] = s;
+  }
+  return t;
+}
+}  // namespace
+
+template <typename T>
+void multOut(lanczosDecomp<T> &L, eigenDecomp<T> &E, adjMatrix &, bool Qtrans) {
+  const std::size_t n = L.get_n();
+  const unsigned k = L.get_krylov();
+  const std::vector<T> t = small_part(E.eigenvalues, E.eigenvectors, k, L.x_norm);
+  if (Qtrans) {
+    // ans = sum_j t_j q_j over contiguous vectors: stream each vector once
+    for (std::size_t i = 0; i < n; ++i) L.ans[i] = 0;
+    for (unsigned j = 0; j < k; ++j) {
+      const T *q = L.Q + static_cast<std::size_t>(j) * n;
+      const T tj = t[j];
+      for (std::size_t i = 0; i < n; ++i) L.ans[i] += tj * q[i];
+    }
+  } else {
+    for (std::size_t i = 0; i < n; ++i) {
+      const T *row = L.Q + i * k;
+      T s = 0;
+      for (unsigned j = 0; j < k; ++j) s += row[j] * t[j];
+      L.ans[i] = s;
+    }
+  }
+}
+
+template <typename T>
+void cu_multOut(lanczosDecomp<T> &L, eigenDecomp<T> &E, adjMatrix &, bool) {
+  if (!L.on_device()) throw std::logic_error("cu_multOut: the decomposition has no device-resident basis");
+  const unsigned k = L.get_krylov();
+  const std::vector<T> t = small_part(E.eigenvalues, E.eigenvectors, k, L.x_norm);
+  std::vector<double> td(t.begin(), t.end()), out(L.get_n());
+  if (lzx_multout_f64(L.engine, td.data(), k, out.data()) != LZX_OK)
+    throw std::runtime_error(std::string("lzx_multout_f64: ") + lzx_last_error());
+  for (std::size_t i = 0; i < out.size(); ++i) L.ans[i] = static_cast<T>(out[i]);
+}
+
+template void multOut(lanczosDecomp<double> &, eigenDecomp<double> &, adjMatrix &, bool);
+template void multOut(lanczosDecomp<float> &, eigenDecomp<float> &, adjMatrix &, bool);
+template void cu_multOut(lanczosDecomp<double> &, eigenDecomp<double> &, adjMatrix &, bool);
+template void cu_multOut(lanczosDecomp<float> &, eigenDecomp<float> &, adjMatrix &, bool);

@@ -1,0 +1,45 @@
+"""Row partition of the multi-GPU Lanczos loop, stated in numpy (host-side mirror of the rules in
+csrc/lzx_graph.hip: lzx_graph_prepare steps 1-2).  Used by bench reporting and by the gloo tests that
+rehearse the N > 1 exchange pattern on CPU.
+
+Rules (identical on every rank, no communication needed to agree on them):
+  * vertices are ranked by degree, descending, ties by the caller's id (stable);
+  * degree rank r is owned by rank r % world, at local row r // world;
+  * every rank's slice of an exchanged vector is n_loc_pad = round_up(ceil(n / world), 64) long, so the
+    all-gather moves equal-sized slices; degree rank r sits at position (r % world) * n_loc_pad + r // world.
+Replaces the reference's split at rows0 = 0.5 * n (parallel-two-cards/lib/cu_lanczos.cu:62-64), which
+balances rows, not work.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SLICE = 64
+
+
+def degree_order(row_ptr: np.ndarray) -> np.ndarray:
+    """order[r] = caller's id of the vertex with degree rank r."""
+    deg = np.diff(np.asarray(row_ptr).astype(np.int64))
+    return np.argsort(-deg, kind="stable")
+
+
+def slice_len(n: int, world: int) -> int:
+    per = -(-n // world)
+    return -(-per // SLICE) * SLICE
+
+
+def positions(n: int, world: int) -> np.ndarray:
+    """pos[r] = position of degree rank r in the full-length exchange layout."""
+    r = np.arange(n, dtype=np.int64)
+    return (r % world) * slice_len(n, world) + r // world
+
+
+def local_vertices(order: np.ndarray, world: int, rank: int) -> np.ndarray:
+    """Caller's ids of the rows rank `rank` owns, in local row order."""
+    return order[rank::world]
+
+
+def nnz_per_rank(row_ptr: np.ndarray, world: int) -> np.ndarray:
+    deg = np.diff(np.asarray(row_ptr).astype(np.int64))
+    order = degree_order(row_ptr)
+    return np.array([deg[order[p::world]].sum() for p in range(world)])

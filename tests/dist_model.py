@@ -1,0 +1,63 @@
+"""The N > 1 Lanczos loop with the SAME partition, layout and exchange pattern as liblzx.so's multi-rank
+path (csrc/lzx_api.hip: lanczos_loop; csrc/lzx_comm.hip), stated over torch.distributed so that it can be
+rehearsed on CPU with the gloo backend.  The local SpMV here is the test oracle's row sums -- this file is
+test infrastructure, not a product path."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
+    """Returns (alpha, beta, gathered full-length q vectors (k, n) in the caller's order) on every rank."""
+    P = pkg_partition
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = len(row_ptr) - 1
+    order = P.degree_order(row_ptr)
+    pos = P.positions(n, world)                 # degree rank -> position in the exchange layout
+    L = P.slice_len(n, world)
+    pos_of_old = np.empty(n, dtype=np.int64)
+    pos_of_old[order] = pos
+    mine = P.local_vertices(order, world, rank)  # caller's ids of my rows, local order
+    rp = row_ptr.astype(np.int64)
+    # my rows' columns translated to exchange-layout positions, caller's column order kept
+    seg = [pos_of_old[col_idx[rp[o]:rp[o + 1]].astype(np.int64)] for o in mine]
+
+    def spmv_local(xfull):
+        out = np.zeros(L)
+        for l, cols in enumerate(seg):
+            acc = 0.0
+            for c in cols:                       # left-to-right, as serial/lib/SPMV.cc
+                acc += xfull[c]
+            out[l] = acc
+        return out
+
+    def allreduce(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item())
+
+    def allgather(loc):
+        outs = [torch.empty(L, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(outs, torch.from_numpy(np.ascontiguousarray(loc)))
+        return torch.cat(outs).numpy()
+
+    xn = np.sqrt(np.sum(x0 * x0))
+    xfull = np.zeros(world * L)
+    xfull[pos_of_old] = x0 / xn
+    q = xfull[rank * L:(rank + 1) * L].copy()
+    q_prev = np.zeros(L)
+    alpha, beta = np.zeros(k), np.zeros(max(k - 1, 1))
+    Q = np.zeros((k, n))
+    for j in range(k):
+        Q[j] = xfull[pos_of_old]
+        v = spmv_local(xfull)
+        alpha[j] = allreduce(float(v @ q))
+        if j == k - 1:
+            break
+        v = v - alpha[j] * q
+        if j > 0:
+            v = v - beta[j - 1] * q_prev
+        beta[j] = np.sqrt(allreduce(float(v @ v)))
+        q_prev, q = q, v / beta[j]
+        xfull = allgather(q)
+    return alpha, beta[:k - 1], Q, xn

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library loads without a GPU and exports exactly what include/lzx.h declares; calls
+that need a GPU fail loudly (no silent fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "lzx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lzx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    declared = header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"liblzx.so does not export {name}"
+    bound = sorted(n for n, _, _ in pkg.SYMBOLS)
+    assert bound == declared, "ctypes table and header disagree"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (lzx_[a-z0-9_]+)", out))
+    assert set(declared) <= exported
+
+
+def test_product_never_links_the_oracle(pkg):
+    out = subprocess.check_output(["ldd", pkg.LIB_PATH], text=True)
+    assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "msc-hpc-final-project_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cc", ".h")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                assert "liboracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_no_gpu_fails_loudly(pkg):
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = os.path.exists("/dev/kfd")
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.LzxError):
+        pkg.Engine(0)
+
+
+def test_argument_errors_without_gpu(pkg):
+    L = pkg.lib()
+    assert L.lzx_create(None, 0) == -1                      # LZX_ERR_ARG
+    assert b"null" in L.lzx_last_error()
+    assert L.lzx_set_option(None, b"hub_entries", 1) == -1
+    assert L.lzx_sync(None) == -1

@@ -1,0 +1,96 @@
+"""GPU: golden vectors through the C ABI, the C++ drop-in classes' device path, the `final` CLI and bench.py."""
+import ctypes
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "msc-hpc-final-project_amd", "host")
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def write_pairs(path, n, pairs):
+    with open(path, "w") as f:
+        f.write(f"{n} {n} {len(pairs)}\n")
+        np.savetxt(f, pairs, fmt="%d")
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(q)[:-4] for q in GOLDEN])
+def test_golden_through_c_abi(pkg, oracle, path):
+    """Reference-derived fixtures: SpMV bit-exact (split rows 1e-13), centrality vector within 1e-10."""
+    O = oracle
+    g = np.load(path)
+    n, k = int(g["mtx_n"]), int(g["k"])
+    eng = pkg.Engine(0)
+    eng.set_graph_csr32(g["ref_row_offset"], g["ref_col_idx"])       # parallel-final's `unsigned` arrays
+    y = eng.spmv(g["x"])
+    deg = np.diff(g["ref_row_offset"].astype(np.int64))
+    order = np.argsort(-deg, kind="stable")
+    n_split = -(-int((deg > 1024).sum()) // 64) * 64
+    body = np.ones(n, dtype=bool)
+    body[order[:n_split]] = False
+    assert np.array_equal(y[body], g["ref_spmv"][body])
+    assert np.allclose(y, g["ref_spmv"], rtol=1e-13, atol=0)
+    a, b, Q, xn, _ = eng.lanczos(np.ones(n), k)
+    assert abs(a[0] - g["alpha"][0]) <= 1e-12 * abs(g["alpha"][0])
+    lam, V = O.eigen(a, b)
+    ans = eng.multout(V @ (np.exp(lam) * (xn * V[0, :])))
+    assert np.abs(ans - g["ans"]).max() <= 1e-10 * np.abs(g["ans"]).max()
+    assert np.abs(ans - g["expm_ref"]).max() <= 1e-10 * np.abs(g["expm_ref"]).max()
+    eng.close()
+
+
+def test_cpp_classes_device_path(pkg, tmp_path):
+    """lanczosDecomp<double>(A, k, x, cuda=true) + eigenDecomp + multOut / cu_multOut vs the fixture."""
+    pkg.lib()
+    H = ctypes.CDLL(os.path.join(HOST_DIR, "libmschpc_host.so"))
+    H.host_expm_file.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_uint, _f64p, _f64p]
+    H.host_expm_file.restype = ctypes.c_long
+    H.host_last_error.restype = ctypes.c_char_p
+    for path in GOLDEN[:3]:
+        g = np.load(path)
+        n, k = int(g["mtx_n"]), int(g["k"])
+        mtx = str(tmp_path / "g.mtx")
+        write_pairs(mtx, n, g["mtx_pairs"])
+        for device_multout in (0, 1):
+            ans = np.zeros(n)
+            rc = H.host_expm_file(mtx.encode(), k, 1, device_multout, ans.ctypes.data_as(_f64p), n, None, None)
+            assert rc == n, H.host_last_error()
+            assert np.abs(ans - g["ans"]).max() <= 1e-10 * np.abs(g["ans"]).max()
+
+
+def test_final_cli(tmp_path):
+    g = np.load(GOLDEN[0])
+    n = int(g["mtx_n"])
+    mtx = str(tmp_path / "graph.mtx")
+    write_pairs(mtx, n, g["mtx_pairs"])
+    out = subprocess.run([os.path.join(HOST_DIR, "final"), "-f", mtx, "-k", "20"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "TIMING" in out.stdout and "ERROR CHECKING" in out.stdout and "Lanczos" in out.stdout
+    rel = [l for l in out.stdout.splitlines() if l.startswith("Relative inf-norm")]
+    assert rel and float(rel[0].split("=")[1]) <= 1e-10
+    ans = np.loadtxt(mtx + ".ans20.txt")
+    assert np.abs(ans - g["ans"]).max() <= 1e-5 * np.abs(g["ans"]).max()    # file holds 6 significant digits
+
+
+def test_bench_contract_small_workload():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--steps", "20",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["steps"] == 20 and j["n_gpus"] == 1 and j["dtype"] == "f64" and j["value"] > 0
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1

@@ -1,0 +1,105 @@
+"""CPU: the C++ drop-in classes (msc-hpc-final-project_amd/host), driven through host_capi.cc."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_SO = os.path.join(ROOT, "msc-hpc-final-project_amd", "host", "libmschpc_host.so")
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="module")
+def host(pkg):
+    pkg.lib()  # liblzx.so first (RTLD_GLOBAL), then the host library that links it
+    H = ctypes.CDLL(HOST_SO)
+    H.host_last_error.restype = ctypes.c_char_p
+    H.host_symtridiag.argtypes = [ctypes.c_int, _f64p, _f64p, _f64p]
+    H.host_expm_file.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_uint, _f64p, _f64p]
+    H.host_expm_file.restype = ctypes.c_long
+    H.host_load_csr.argtypes = [ctypes.c_char_p, _u32p, _u32p, ctypes.c_uint]
+    H.host_load_csr.restype = ctypes.c_long
+    H.host_gen_csr.argtypes = [ctypes.c_char, ctypes.c_uint, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_ulonglong, _u32p, _u32p, ctypes.c_uint]
+    H.host_gen_csr.restype = ctypes.c_long
+    return H
+
+
+def p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def write_pairs(path, n, pairs):
+    with open(path, "w") as f:
+        f.write(f"{n} {n} {len(pairs)}\n")
+        np.savetxt(f, pairs, fmt="%d")
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(q)[:-4] for q in GOLDEN])
+def test_loader_and_cpu_pipeline_match_reference_fixture(host, tmp_path, path):
+    g = np.load(path)
+    n, k = int(g["mtx_n"]), int(g["k"])
+    mtx = str(tmp_path / "g.mtx")
+    write_pairs(mtx, n, g["mtx_pairs"])
+    ro = np.zeros(n + 1, dtype=np.uint32)
+    ci = np.zeros(2 * len(g["mtx_pairs"]) + 1, dtype=np.uint32)
+    edges = host.host_load_csr(mtx.encode(), p(ro, _u32p), p(ci, _u32p), len(ci))
+    assert edges == int(g["ref_edge_count"]), host.host_last_error()
+    assert np.array_equal(ro, g["ref_row_offset"]) and np.array_equal(ci[:2 * edges], g["ref_col_idx"])
+    ans = np.zeros(n)
+    alpha, beta = np.zeros(k), np.zeros(k)
+    rc = host.host_expm_file(mtx.encode(), k, 0, 0, p(ans, _f64p), n, p(alpha, _f64p), p(beta, _f64p))
+    assert rc == n, host.host_last_error()
+    # CPU decompose(): same operation order as the reference -> identical coefficients
+    assert np.array_equal(alpha, g["alpha"]) and np.array_equal(beta[:k - 1], g["beta"])
+    # own QL eigensolver + plain-loop multOut vs LAPACK + BLAS: rounding level
+    assert np.abs(ans - g["ans"]).max() <= 1e-12 * np.abs(g["ans"]).max()
+
+
+def test_symtridiag_matches_lapack(host):
+    from scipy.linalg import eigh_tridiagonal
+    rng = np.random.default_rng(3)
+    for k in (1, 2, 7, 50, 120):
+        d = rng.normal(size=k) * 10
+        e = rng.random(max(k - 1, 1)) * 5
+        dd = d.copy()
+        z = np.zeros((k, k))
+        assert host.host_symtridiag(k, p(dd, _f64p), p(e, _f64p), p(z, _f64p)) == 0
+        if k == 1:
+            assert dd[0] == d[0] and z[0, 0] == 1.0
+            continue
+        lam, V = eigh_tridiagonal(d, e[:k - 1], lapack_driver="stev")
+        assert np.abs(dd - lam).max() <= 1e-12 * max(1.0, np.abs(lam).max())
+        T = np.diag(d) + np.diag(e[:k - 1], 1) + np.diag(e[:k - 1], -1)
+        assert np.abs(T @ z - z * dd).max() <= 1e-11 * np.abs(lam).max()
+        assert np.abs(z.T @ z - np.eye(k)).max() <= 1e-12
+
+
+def test_generators_match_oracle_spec(host, oracle):
+    O = oracle
+    ro_ref, ci_ref = O.gen_rmat(12, 3000, 40000, 77)
+    ro = np.zeros(3001, dtype=np.uint32)
+    ci = np.zeros(80001, dtype=np.uint32)
+    e = host.host_gen_csr(b"m", 12, 3000, 40000, 77, p(ro, _u32p), p(ci, _u32p), len(ci))
+    assert e == len(ci_ref) // 2
+    assert np.array_equal(ro, ro_ref.astype(np.uint32)) and np.array_equal(ci[:2 * e], ci_ref)
+    ro_ref, ci_ref = O.gen_er(2000, 9000, 1234)
+    ro = np.zeros(2001, dtype=np.uint32)
+    ci = np.zeros(18001, dtype=np.uint32)
+    e = host.host_gen_csr(b"r", 0, 2000, 9000, 1234, p(ro, _u32p), p(ci, _u32p), len(ci))
+    assert e == len(ci_ref) // 2 and np.array_equal(ci[:2 * e], ci_ref)
+    ro = np.zeros(501, dtype=np.uint32)
+    ci = np.zeros(6001, dtype=np.uint32)
+    e = host.host_gen_csr(b"b", 0, 500, 5, 1234, p(ro, _u32p), p(ci, _u32p), len(ci))
+    deg = np.diff(ro.astype(np.int64))
+    assert e > 0 and deg.min() >= 5 and deg.sum() == 2 * e     # every vertex attaches to >= m others
+
+
+def test_missing_file_reports_error(host):
+    ans = np.zeros(4)
+    assert host.host_expm_file(b"/nonexistent/graph.mtx", 3, 0, 0, p(ans, _f64p), 4, None, None) == -1
+    assert b"cannot open" in host.host_last_error()
