@@ -37,6 +37,19 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X datasheet, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(workload: str, world: int):
+    """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (bench.py cannot wrap itself in the
+    profiler); None when no pass exists for this workload / rank count."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path)).get(workload)
+        return (d["hbm_bytes_per_launch"], d["source"]) if d else (None, None)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(eng, O, budget_s: float = 20.0):
     """The oracle's restatement of serial/ (single thread) on the SAME graph, a bounded number of iterations."""
     rp, ci = eng.get_graph_csr()
@@ -167,7 +180,8 @@ def main():
                 "peak": HBM_PEAK_GBS * world,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_GBS * world),
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload, world)[0],
+                "traffic_source": pmc_traffic(args.workload, world)[1],
                 "algorithmic_bytes_per_spmv": spmv_bytes_total,
                 "avg_spmv_ms": spmv_avg_ms,
                 "spmv_share_of_loop": spmv_ms_max / (elapsed * 1e3),

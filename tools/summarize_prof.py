@@ -1,0 +1,59 @@
+"""tools/summarize_prof.py <gpurun_out/prof_dir> <tag> -- condenses a rocprofv3 run (kernel-trace stats + separate
+FETCH_SIZE / WRITE_SIZE passes, as MI355X_MICROARCH.md's HBM section prescribes) into profiles/<tag>_*."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def short(name):
+    return name if len(name) < 120 else name[:117] + "..."
+
+
+stats = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                        r["MaxNs"], r["StdDev"]])
+
+pmc = {}
+for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    if not files:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        if k.startswith(("void k_", "k_")):
+            pmc.setdefault(k, {})[counter + "_KiB_avg_per_launch"] = sum(v) / len(v)
+            pmc[k][counter + "_launches"] = len(v)
+# HBM traffic per launch: FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM section):
+# doubled for the read side; WRITE_SIZE is exact.
+for k, d in pmc.items():
+    f = d.get("FETCH_SIZE_KiB_avg_per_launch")
+    w = d.get("WRITE_SIZE_KiB_avg_per_launch")
+    if f is not None and w is not None:
+        d["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
+        d["hbm_bytes_per_launch_raw"] = (f + w) * 1024.0
+bench = {}
+for name in ("bench_kt.json", "bench_fetch.json", "bench_write.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        lines = [l for l in open(p) if l.startswith("{")]
+        if lines:
+            bench[name] = json.loads(lines[-1])
+json.dump({"pmc": pmc, "bench_lines": bench}, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1)
+print("wrote", os.listdir(out_dir))
