@@ -63,6 +63,7 @@ typedef struct lzx_graph_info {
     uint64_t nnz_local;   /* entries in those rows                               */
     uint64_t long_rows;   /* local rows handled by the split-row path            */
     uint64_t sell_padded; /* entries of the sliced-ELL body including padding    */
+    uint64_t pb_entries;  /* local entries handled by the propagation-blocked passes (0 = mode off) */
     uint32_t hub_entries; /* x entries staged in LDS per workgroup               */
     uint32_t world, rank;
 } lzx_graph_info;
@@ -160,8 +161,12 @@ int lzx_multout_f64_local(lzx_handle *hs, int world, const double *t, uint32_t k
  * average and minimum HIP-event time of one SpMV (all its kernels) in milliseconds.              */
 int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
 
-/* Tuning knobs (0 = default).  hub_entries: how many of the highest-degree vertices' x values each
- * workgroup stages in LDS (0 disables staging when `set` is non-zero).                           */
+/* Tuning knobs, to be set before the graph is handed over:
+ *   "hub_entries"           x values of the highest-degree vertices staged in LDS by the SpMV (0 = none)
+ *   "propagation_blocking"  1 / 0 force the two-pass blocked treatment of non-staged columns on / off
+ *                           (default: on for graphs whose x does not fit the L2s); with it off the sliced-ELL
+ *                           rows are summed in the reference's order and come out bit-identical to serial/
+ *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask"   experiment knobs (tools/perf_probe.py)        */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);
 
 #ifdef __cplusplus

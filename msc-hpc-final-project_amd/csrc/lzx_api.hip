@@ -7,6 +7,7 @@
 // *alpha_d: parallel-final/lib/cu_lanczos.cu:108,113,123).
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -81,6 +82,9 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "wgs_per_cu")) c->wgs_per_cu_opt = value;
     else if (!strcmp(name, "nt_index_loads")) c->nt_opt = value;
     else if (!strcmp(name, "long_row")) c->long_row_opt = value;
+    else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
+    else if (!strcmp(name, "pb_debug")) c->pb_debug = value;
+    else if (!strcmp(name, "pb_target")) c->pb_target_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
@@ -307,7 +311,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         memset(stats, 0, sizeof *stats);
         stats->loop_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats->iters = k;
-        stats->spmv_kernels = 1 + (c0->fin_grid > 0 ? 1 : 0);
+        stats->spmv_kernels = 1 + (c0->fin_grid > 0 ? 1 : 0) + (c0->pb ? 2 : 0);
         stats->spmv_bytes = spmv_algorithmic_bytes(c0);
         stats->spmv_ms_min = 1e300;
         for (size_t i = 1; i < mk.used; ++i) {
@@ -521,5 +525,25 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
     }
     *avg_ms = total / reps;
     if (min_ms) *min_ms = best;
+    if (getenv("LZX_TRACE_SPMV")) {
+        // one more SpMV with marks between its kernels: hub/body, split-row finish, scatter, gather (+finish)
+        for (auto &ev : c->trace_ev)
+            if (!ev) LZX_HIP(hipEventCreate(&ev));
+        c->trace = true;
+        for (auto &ev : c->trace_ev) LZX_HIP(hipEventRecord(ev, c->stream));
+        int rc = lzx_launch_spmv(c, l);
+        c->trace = false;
+        LZX_TRY(rc);
+        LZX_HIP(hipStreamSynchronize(c->stream));
+        float t[4] = {0, 0, 0, 0};
+        (void)hipEventElapsedTime(&t[0], c->trace_ev[0], c->trace_ev[1]);
+        (void)hipEventElapsedTime(&t[1], c->trace_ev[1], c->trace_ev[2]);
+        if (c->pb) {
+            (void)hipEventElapsedTime(&t[2], c->trace_ev[2], c->trace_ev[3]);
+            (void)hipEventElapsedTime(&t[3], c->trace_ev[3], c->trace_ev[4]);
+        }
+        fprintf(stderr, "[lzx trace] k_spmv %.4f ms  long_finish %.4f ms  pb_scatter %.4f ms  pb_gather(+finish) %.4f ms\n",
+                t[0], t[1], t[2], t[3]);
+    }
     return LZX_OK;
 }

@@ -56,6 +56,7 @@ int lzx_graph_release(lzx_ctx *c)
     dev_free(c->d_io);
     dev_free(c->d_partials);
     dev_free(c->d_partials2);
+    lzx_pb_release(c);
     c->q_cols = 0;
     c->k_last = 0;
     c->n = c->nnz = 0;
@@ -141,6 +142,76 @@ __global__ void k_fill_long(const u64 *row_ptr, const u32 *col_idx, const u32 *c
         long_cols[beg + k] = (k < d) ? code_of_old[col_idx[base + k]] : sentinel;
 }
 
+// entries of each local row whose column is staged in LDS (code < hub); one wavefront per row
+__global__ void __launch_bounds__(64)
+k_row_hub_count(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, const u32 *old_of_local,
+                const u32 *deg_local, u32 hub, u32 *hub_deg, u32 *nonhub_deg)
+{
+    const u32 l = blockIdx.x, lane = threadIdx.x;
+    const u32 d = deg_local[l];
+    const u64 base = row_ptr[old_of_local[l]];
+    u32 cnt = 0;
+    for (u32 k = lane; k < d; k += 64) cnt += code_of_old[col_idx[base + k]] < hub;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) {
+        hub_deg[l] = cnt;
+        nonhub_deg[l] = d - cnt;
+    }
+}
+
+// Hub-only variants of the two fills (propagation-blocking mode): keep, in order, the entries with
+// code < hub; pad with `pad_code` (an LDS slot that holds 0).
+__global__ void k_fill_sell_hub(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old,
+                                const u32 *old_of_local, const u32 *deg_local, u32 n_loc_real, u32 row0,
+                                u32 n_loc_pad, const u64 *slice_off, const u32 *slice_w, u32 *cols, u32 hub,
+                                u32 pad_code)
+{
+    const u32 l = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_loc_pad) return;
+    const u32 s = (l - row0) >> 6, lane = (l - row0) & 63;
+    const u32 w = slice_w[s];
+    u32 *out = cols + slice_off[s] + (size_t)lane * 4;   // packet p of this lane: out[p * 256 .. +4)
+    u32 kept = 0;
+    if (l < n_loc_real) {
+        const u32 d = deg_local[l];
+        const u64 base = row_ptr[old_of_local[l]];
+        for (u32 k = 0; k < d; ++k) {
+            const u32 cde = code_of_old[col_idx[base + k]];
+            if (cde < hub) {
+                out[(size_t)(kept >> 2) * 256 + (kept & 3)] = cde;
+                ++kept;
+            }
+        }
+    }
+    for (; kept < w; ++kept) out[(size_t)(kept >> 2) * 256 + (kept & 3)] = pad_code;
+}
+
+__global__ void __launch_bounds__(64)
+k_fill_long_hub(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, const u32 *old_of_local,
+                const u32 *deg_local, u32 n_loc_real, const u64 *long_ptr, u32 *long_cols, u32 hub, u32 pad_code)
+{
+    const u32 r = blockIdx.x, lane = threadIdx.x;
+    const u64 beg = long_ptr[r], end = long_ptr[r + 1];
+    u64 out = beg;
+    if (r < n_loc_real) {
+        const u32 d = deg_local[r];
+        const u64 base = row_ptr[old_of_local[r]];
+        for (u32 k0 = 0; k0 < d; k0 += 64) {
+            const u32 k = k0 + lane;
+            u32 cde = 0;
+            bool keep = false;
+            if (k < d) {
+                cde = code_of_old[col_idx[base + k]];
+                keep = cde < hub;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) long_cols[out + __popcll(m & ((1ull << lane) - 1ull))] = cde;
+            out += __popcll(m);
+        }
+    }
+    for (u64 k = out + lane; k < end; k += 64) long_cols[k] = pad_code;
+}
+
 static u32 round_up(u32 a, u32 m) { return (a + m - 1) / m * m; }
 
 int lzx_graph_prepare(lzx_ctx *c)
@@ -159,27 +230,36 @@ int lzx_graph_prepare(lzx_ctx *c)
     c->n_loc_real = (rank < n) ? (u32)((n - rank + world - 1) / world) : 0;
     if (c->xlen + 65536 >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "exchange layout does not fit 32-bit codes");
 
-    // hub entries staged in LDS: default 8192 (64 KiB -> two 1024-thread workgroups per CU)
-    u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : 8192;
+    // Propagation blocking (lzx_pb.hip) for every entry whose column is not staged in LDS: worth its two extra
+    // launches once x no longer sits in the L2s.  -1 = decide here.
+    // Measured: not yet ahead of the plain gather on the benchmark graphs, so off unless asked for.
+    bool pb = c->pb_opt > 0;
+    // hub entries staged in LDS by k_spmv: 8192 (64 KiB, two workgroups per CU) when k_spmv also gathers from
+    // memory; 16384 (128 KiB, one per CU) in propagation-blocking mode, where it only ever reads LDS.
+    u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : (pb ? 16384 : 8192);
     hub = std::min<u64>(hub, n);
     hub = std::min<u64>(hub, 20000);  // 160 KiB LDS per CU
     hub &= ~1ull;
-    c->hub = (u32)hub;
+    if (hub == 0 || hub >= n) pb = false;   // nothing staged, or everything staged: nothing to block
+    c->hub_real = (u32)hub;
+    c->hub = (u32)hub + (pb ? 2 : 0);       // PB mode: two zero slots behind the staged values (padding target)
     c->spmv_lds = ((size_t)c->hub + LZX_SPMV_BLOCK / 64) * sizeof(double);
-    const u32 sentinel = c->hub + (u32)((u64)world * c->n_loc_pad);
+    const u32 sentinel = pb ? c->hub_real : c->hub + (u32)((u64)world * c->n_loc_pad);
 
     // ---- 1. degree ranking ----
     u32 *d_deg = nullptr, *d_ids = nullptr, *d_sdeg = nullptr, *d_sids = nullptr, *d_code = nullptr;
     u32 *d_old_of_local = nullptr, *d_deg_local = nullptr;
+    u32 *d_hub_deg = nullptr, *d_nh_deg = nullptr, *d_nh_off = nullptr;
     void *d_tmp = nullptr;
     u64 *d_long_ptr = nullptr;
     int rc = LZX_OK;
-    std::vector<u32> degl;
+    std::vector<u32> degl, h_nh;
     std::vector<u64> h_slice_off, h_long_ptr, h_item_beg;
     std::vector<u32> h_slice_w, h_item_len, h_item_first;
     auto cleanup = [&]() {
         dev_free(d_deg); dev_free(d_ids); dev_free(d_sdeg); dev_free(d_sids); dev_free(d_code);
         dev_free(d_old_of_local); dev_free(d_deg_local); dev_free(d_long_ptr);
+        dev_free(d_hub_deg); dev_free(d_nh_deg); dev_free(d_nh_off);
         if (d_tmp) (void)hipFree(d_tmp);
         d_tmp = nullptr;
     };
@@ -201,7 +281,7 @@ int lzx_graph_prepare(lzx_ctx *c)
     PREP_HIP(hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tmp_bytes, d_deg, d_sdeg, d_ids, d_sids,
                                                          (u64)n, 0, 32, st));
     hipLaunchKernelGGL(k_rank_maps, dim3(gb), dim3(256), 0, st, d_sids, c->d_gidx_of_old, d_code, n,
-                       world, c->n_loc_pad, c->hub);
+                       world, c->n_loc_pad, c->hub_real);
     {
         u32 md = 0;
         PREP_HIP(hipMemcpyAsync(&md, d_sdeg, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -219,15 +299,45 @@ int lzx_graph_prepare(lzx_ctx *c)
     if (c->n_loc_real)
         PREP_HIP(hipMemcpyAsync(degl.data(), d_deg_local, sizeof(u32) * c->n_loc_real, hipMemcpyDeviceToHost, st));
     PREP_HIP(hipStreamSynchronize(st));
+    c->nnz_local = 0;
+    for (u32 l = 0; l < c->n_loc_real; ++l) c->nnz_local += degl[l];
+
+    // propagation-blocking mode: k_spmv keeps only the hub entries of each row; `degl` becomes that count
+    u64 pb_total = 0;
+    if (pb && c->n_loc_real) {
+        PREP(dev_alloc(&d_hub_deg, c->n_loc_real)); PREP(dev_alloc(&d_nh_deg, (u64)c->n_loc_real + 1));
+        PREP(dev_alloc(&d_nh_off, (u64)c->n_loc_real + 1));
+        PREP_HIP(hipMemsetAsync(d_nh_deg, 0, sizeof(u32) * ((u64)c->n_loc_real + 1), st));
+        hipLaunchKernelGGL(k_row_hub_count, dim3(c->n_loc_real), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
+                           d_old_of_local, d_deg_local, c->hub_real, d_hub_deg, d_nh_deg);
+        h_nh.assign(c->n_loc_real, 0);
+        PREP_HIP(hipMemcpyAsync(degl.data(), d_hub_deg, sizeof(u32) * c->n_loc_real, hipMemcpyDeviceToHost, st));
+        PREP_HIP(hipMemcpyAsync(h_nh.data(), d_nh_deg, sizeof(u32) * c->n_loc_real, hipMemcpyDeviceToHost, st));
+        PREP_HIP(hipStreamSynchronize(st));
+        u64 hub_total = 0;
+        for (u32 l = 0; l < c->n_loc_real; ++l) hub_total += degl[l];
+        pb_total = c->nnz_local - hub_total;
+        if (pb_total == 0 || pb_total >= (1ull << 32) - 8) pb = false;
+        if (pb) {
+            size_t sb = 0;
+            PREP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, d_nh_deg, d_nh_off, (u64)c->n_loc_real + 1, st));
+            if (d_tmp) { (void)hipFree(d_tmp); d_tmp = nullptr; }
+            PREP_HIP(hipMalloc(&d_tmp, sb ? sb : 16));
+            PREP_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, sb, d_nh_deg, d_nh_off, (u64)c->n_loc_real + 1, st));
+        } else {
+            lzx_set_error("internal: propagation blocking chosen but not applicable");
+            cleanup();
+            return LZX_ERR_STATE;
+        }
+    } else {
+        pb = false;
+    }
 
     // ---- 3. host: split rows / slices (local rows are sorted by degree, descending) ----
     const u32 long_thr = c->long_row_opt > 0 ? (u32)c->long_row_opt : LZX_LONG_ROW;
     u32 n_long = 0;
-    c->nnz_local = 0;
-    for (u32 l = 0; l < c->n_loc_real; ++l) {
-        c->nnz_local += degl[l];
+    for (u32 l = 0; l < c->n_loc_real; ++l)
         if (degl[l] > long_thr) n_long = l + 1;
-    }
     c->n_long_true = n_long;
     c->n_long64 = std::min(round_up(n_long, LZX_SLICE), c->n_loc_pad);
     c->n_slices = (c->n_loc_pad - c->n_long64) / LZX_SLICE;
@@ -251,7 +361,9 @@ int lzx_graph_prepare(lzx_ctx *c)
     h_slice_w.assign(c->n_slices, 0);
     u64 off = 0;
     for (u32 s = 0; s < c->n_slices; ++s) {
-        const u32 w = round_up(degl[c->n_long64 + s * LZX_SLICE], 4);
+        u32 widest = 0;  // rows are degree-sorted, but in PB mode `degl` counts hub entries only: take the max
+        for (u32 l = 0; l < LZX_SLICE; ++l) widest = std::max(widest, degl[c->n_long64 + s * LZX_SLICE + l]);
+        const u32 w = round_up(widest, 4);
         h_slice_off[s] = off;
         h_slice_w[s] = w;
         off += (u64)w * LZX_SLICE;
@@ -278,15 +390,29 @@ int lzx_graph_prepare(lzx_ctx *c)
     PREP_HIP(hipMemcpyAsync(d_long_ptr, h_long_ptr.data(), sizeof(u64) * ((size_t)c->n_long64 + 1), hipMemcpyHostToDevice, st));
     if (c->n_slices) {
         const u32 rows = c->n_loc_pad - c->n_long64;
-        hipLaunchKernelGGL(k_fill_sell, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx,
-                           d_code, d_old_of_local, d_deg_local, c->n_loc_real, c->n_long64, c->n_loc_pad,
-                           c->d_slice_off, c->d_slice_w, c->d_sell_cols, sentinel);
+        if (pb)
+            hipLaunchKernelGGL(k_fill_sell_hub, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx,
+                               d_code, d_old_of_local, d_deg_local, c->n_loc_real, c->n_long64, c->n_loc_pad,
+                               c->d_slice_off, c->d_slice_w, c->d_sell_cols, c->hub_real, sentinel);
+        else
+            hipLaunchKernelGGL(k_fill_sell, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx,
+                               d_code, d_old_of_local, d_deg_local, c->n_loc_real, c->n_long64, c->n_loc_pad,
+                               c->d_slice_off, c->d_slice_w, c->d_sell_cols, sentinel);
     }
     if (c->n_long64) {
-        hipLaunchKernelGGL(k_fill_long, dim3(c->n_long64), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
-                           d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, c->d_long_cols, sentinel);
+        if (pb)
+            hipLaunchKernelGGL(k_fill_long_hub, dim3(c->n_long64), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
+                               d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, c->d_long_cols, c->hub_real,
+                               sentinel);
+        else
+            hipLaunchKernelGGL(k_fill_long, dim3(c->n_long64), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
+                               d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, c->d_long_cols, sentinel);
     }
     PREP_HIP(hipGetLastError());
+    if (pb) {
+        if (d_tmp) { (void)hipFree(d_tmp); d_tmp = nullptr; }
+        PREP(lzx_pb_prepare(c, d_code, d_old_of_local, d_deg_local, d_nh_off, h_nh, pb_total));
+    }
 
     // ---- 5. vectors ----
     PREP(dev_alloc(&c->d_v, c->ldq));
@@ -307,7 +433,7 @@ int lzx_graph_prepare(lzx_ctx *c)
     grid = std::min(grid, std::max(1u, (units + waves_per_wg - 1) / waves_per_wg));
     c->spmv_grid = grid;
     c->fin_grid = (c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
-    c->np_cap = std::max<u32>(c->spmv_grid + c->fin_grid, (u32)c->cu_count * 8) + 8;
+    c->np_cap = std::max<u32>(c->spmv_grid + c->fin_grid + lzx_pb_partials(c), (u32)c->cu_count * 8) + 8;
     PREP(dev_alloc(&c->d_partials, c->np_cap)); PREP(dev_alloc(&c->d_partials2, c->np_cap));
 
     PREP_HIP(hipStreamSynchronize(st));
@@ -529,7 +655,8 @@ extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
     o->nnz_local = c->nnz_local;
     o->long_rows = c->n_long_true;
     o->sell_padded = c->sell_elems + c->long_elems;
-    o->hub_entries = c->hub;
+    o->hub_entries = c->hub_real;
+    o->pb_entries = c->pb ? c->pb_entries : 0;
     o->world = (uint32_t)c->world;
     o->rank = (uint32_t)c->rank;
     return LZX_OK;

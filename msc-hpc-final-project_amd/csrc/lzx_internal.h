@@ -50,6 +50,13 @@ static constexpr u32 LZX_SPMV_BLOCK = 1024;
 static constexpr u32 LZX_VEC_BLOCK = 256;
 // Zero tail behind every full-length vector: the padding column index points here.
 static constexpr u32 LZX_TAIL = 64;
+// Propagation blocking (csrc/lzx_pb.hip): column band staged in LDS by the scatter phase (doubles),
+// rows per wavefront-private LDS y tile in the gather phase, entries per scatter work unit.
+static constexpr u32 LZX_PB_CB = 16384;
+static constexpr u32 LZX_PB_RB = 1024;
+static constexpr u32 LZX_PB_UNIT = 1u << 18;
+static constexpr u32 LZX_PB_TARGET = 16384;   // entries per row band = per gather wavefront
+static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
 
 struct lzx_ctx {
     int device = 0;
@@ -58,6 +65,8 @@ struct lzx_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;       // scratch timing pair
     hipEvent_t ev_phase = nullptr;                    // cross-handle ordering in local-comm mode
     std::vector<hipEvent_t> ev_pool;                  // per-iteration timing events
+    hipEvent_t trace_ev[6] = {};                      // lzx_bench_spmv: marks between the SpMV's kernels
+    bool trace = false;
 
     // ---- communicator ----
     int world = 1, rank = 0;
@@ -81,6 +90,9 @@ struct lzx_ctx {
     int64_t hub_opt = -1;              // user override (-1: default)
     int64_t wgs_per_cu_opt = -1;
     int64_t nt_opt = -1;
+    int64_t pb_opt = -1;               // propagation blocking: -1 auto, 0 off, 1 on
+    int64_t pb_target_opt = -1;        // entries per row band override
+    int64_t pb_debug = 0;              // ablation switches (tools/perf_probe.py): low 4 bits scatter, next 4 gather
     int64_t long_row_opt = -1;         // split-row threshold override
     int64_t phase_mask_opt = 3;        // debug: 1 = split rows only, 2 = body only
 
@@ -101,6 +113,24 @@ struct lzx_ctx {
     u32 *d_item_len = nullptr;         // [n_items] entries (multiple of 4)
     u32 *d_item_first = nullptr;       // [n_long64 + 1] first item of each split row
     double *d_long_partial = nullptr;  // [n_items]
+
+    // propagation-blocked part (every entry whose column is not staged in LDS), see lzx_pb.hip
+    bool pb = false;
+    u32 hub_real = 0;                  // hub entries that carry x values (PB mode adds zero slots behind them)
+    u64 pb_entries = 0;
+    u32 pb_nr = 0;                     // row bands of LZX_PB_RB local rows
+    u32 pb_units = 0;                  // scatter work units
+    uint16_t *d_pb_lcol = nullptr;     // [pb_entries] scatter order: column within its band
+    u32 *d_pb_dst = nullptr;           // [pb_entries] scatter order: slot in d_pb_val (gather order)
+    uint16_t *d_pb_lrow = nullptr;     // [pb_entries] gather order: row within its band
+    double *d_pb_val = nullptr;        // [pb_entries] gathered x values in gather order (scratch)
+    u32 *d_pb_unit = nullptr;          // [pb_units][3] band, begin, end (scatter order)
+    u32 *d_pb_row0 = nullptr;          // [pb_nr + 1] first local row of each row band
+    u32 *d_pb_items = nullptr;         // [pb_n_items][4] row band, begin, end (gather order), slot or ~0
+    u32 *d_pb_multi = nullptr;         // [pb_n_multi][3] row, first slot, slots: rows cut into several items
+    double *d_pb_part = nullptr;       // item totals of those rows
+    u32 pb_n_items = 0, pb_n_multi = 0;
+    u32 pb_gather_grid = 0, pb_finish_grid = 0;
 
     // vectors and scalars
     double *d_v = nullptr;             // [ldq]
@@ -127,6 +157,15 @@ struct lzx_ctx {
 // ---- lzx_graph.hip ----
 int lzx_graph_release(lzx_ctx *c);
 int lzx_graph_prepare(lzx_ctx *c);   // builds this rank's share from d_row_ptr/d_col_idx
+
+// ---- lzx_pb.hip ----
+// Builds the propagation-blocked structure for this rank's non-hub entries. d_nh_off: exclusive prefix of the
+// per-local-row count of non-hub entries (u32, n_loc_real + 1 values).
+int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, const u32 *d_deg_local,
+                   const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total);
+void lzx_pb_release(lzx_ctx *c);
+int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials);
+u32 lzx_pb_partials(const lzx_ctx *c);
 
 // ---- lzx_kernels.hip ----
 struct SpmvLaunch {

@@ -53,7 +53,8 @@ struct SpmvArgs {
     const double *q_loc;
     double *v;
     double *partials;
-    u32 hub;
+    u32 hub;       // LDS slots (staged values + zero slots)
+    u32 hub_real;  // slots that carry x values
     u32 world;
     u32 n_loc_pad;
 };
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
         // `world` strided segments otherwise: degree rank r lives at (r % world) * n_loc_pad + r / world).
         for (u32 i = tid; i < a.hub; i += LZX_SPMV_BLOCK) {
             const u32 g = (a.world == 1) ? i : (i % a.world) * a.n_loc_pad + i / a.world;
-            hubv[i] = a.x[g];
+            hubv[i] = i < a.hub_real ? a.x[g] : 0.0;
         }
         __syncthreads();
     }
@@ -111,7 +112,21 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
         const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + a.item_beg[it]);
         const u32 packets = a.item_len[it] >> 2;
         double acc = 0.0;
-        for (u32 q = lane; q < packets; q += 64) {
+        u32 q = lane;
+        for (; q + 64 < packets; q += 128) {
+            const uint4 c = load_idx4<NT>(p + q), e = load_idx4<NT>(p + q + 64);
+            const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
+            const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
+            const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
+            const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
+            const double x4 = gather<HUB>(e.x, a.x, hubv, a.hub);
+            const double x5 = gather<HUB>(e.y, a.x, hubv, a.hub);
+            const double x6 = gather<HUB>(e.z, a.x, hubv, a.hub);
+            const double x7 = gather<HUB>(e.w, a.x, hubv, a.hub);
+            acc += x0; acc += x1; acc += x2; acc += x3;
+            acc += x4; acc += x5; acc += x6; acc += x7;
+        }
+        for (; q < packets; q += 64) {
             const uint4 c = load_idx4<NT>(p + q);
             const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
             const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
@@ -127,26 +142,63 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
     //      entries one at a time in the caller's column order: the same left-to-right sum as the
     //      reference's spMV (serial/lib/SPMV.cc:24-27), so these rows come out bit-identical to it.
     double dot = 0.0;
-    for (u32 s = w0; s < a.n_slices; s += waves) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + a.slice_off[s]) + lane;
-        const u32 steps = a.slice_w[s] >> 2;
-        double acc = 0.0;
-        u32 i = 0;
-        for (; i + 2 <= steps; i += 2) {
-            const uint4 c0 = load_idx4<NT>(p + (size_t)i * 64);
-            const uint4 c1 = load_idx4<NT>(p + (size_t)(i + 1) * 64);
-            const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
-            const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
-            const double x2 = gather<HUB>(c0.z, a.x, hubv, a.hub);
-            const double x3 = gather<HUB>(c0.w, a.x, hubv, a.hub);
-            const double x4 = gather<HUB>(c1.x, a.x, hubv, a.hub);
-            const double x5 = gather<HUB>(c1.y, a.x, hubv, a.hub);
-            const double x6 = gather<HUB>(c1.z, a.x, hubv, a.hub);
-            const double x7 = gather<HUB>(c1.w, a.x, hubv, a.hub);
-            acc += x0; acc += x1; acc += x2; acc += x3;
-            acc += x4; acc += x5; acc += x6; acc += x7;
+    // Software pipeline across slices: while slice s is summed, the first four index packets of the wave's next
+    // slice are already in flight (after the hub split most slices are only a few packets wide, so without this
+    // every slice pays a full memory round trip on its own).
+    u32 s = w0;
+    bool have = s < a.n_slices;
+    const uint4 *p = nullptr;
+    u32 steps = 0;
+    uint4 pf[4] = {};
+    if (have) {
+        p = reinterpret_cast<const uint4 *>(a.sell_cols + a.slice_off[s]) + lane;
+        steps = a.slice_w[s] >> 2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((u32)u < steps) pf[u] = load_idx4<NT>(p + (size_t)u * 64);
+    }
+    while (have) {
+        const u32 s2 = s + waves;
+        const bool have2 = s2 < a.n_slices;
+        const uint4 *p2 = nullptr;
+        u32 steps2 = 0;
+        uint4 nf[4] = {};
+        if (have2) {
+            p2 = reinterpret_cast<const uint4 *>(a.sell_cols + a.slice_off[s2]) + lane;
+            steps2 = a.slice_w[s2] >> 2;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((u32)u < steps2) nf[u] = load_idx4<NT>(p2 + (size_t)u * 64);
         }
-        if (i < steps) {
+
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if ((u32)u < steps) {
+                const double x0 = gather<HUB>(pf[u].x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(pf[u].y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(pf[u].z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(pf[u].w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
+            }
+        }
+        u32 i = 4;
+        for (; i + 4 <= steps; i += 4) {
+            uint4 c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(p + (size_t)(i + u) * 64);
+            double xv[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[4 * u + 0] = gather<HUB>(c[u].x, a.x, hubv, a.hub);
+                xv[4 * u + 1] = gather<HUB>(c[u].y, a.x, hubv, a.hub);
+                xv[4 * u + 2] = gather<HUB>(c[u].z, a.x, hubv, a.hub);
+                xv[4 * u + 3] = gather<HUB>(c[u].w, a.x, hubv, a.hub);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += xv[u];
+        }
+        for (; i < steps; ++i) {
             const uint4 c0 = load_idx4<NT>(p + (size_t)i * 64);
             const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
             const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
@@ -157,6 +209,13 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
         const u32 row = a.row0 + s * 64 + lane;
         a.v[row] = acc;
         dot += acc * a.q_loc[row];
+
+        s = s2;
+        have = have2;
+        p = p2;
+        steps = steps2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pf[u] = nf[u];
     }
 
     dot = wave_sum(dot);
@@ -283,7 +342,7 @@ static u32 vec_grid(const lzx_ctx *c)
     return need < 1 ? 1 : (need < cap ? need : cap);
 }
 
-u32 lzx_spmv_partials(const lzx_ctx *c) { return c->spmv_grid + c->fin_grid; }
+u32 lzx_spmv_partials(const lzx_ctx *c) { return c->spmv_grid + c->fin_grid + lzx_pb_partials(c); }
 
 template <bool HUB, bool NT>
 static int launch_spmv_t(lzx_ctx *c, const SpmvArgs &a)
@@ -313,9 +372,11 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.v = l.v;
     a.partials = l.partials;
     a.hub = c->hub;
+    a.hub_real = c->hub_real;
     a.world = (u32)c->world;
     a.n_loc_pad = c->n_loc_pad;
     const bool nt = c->nt_opt > 0;
+    if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[0], c->stream));
     if (c->hub > 0) {
         if (nt) LZX_TRY((launch_spmv_t<true, true>(c, a)));
         else    LZX_TRY((launch_spmv_t<true, false>(c, a)));
@@ -323,12 +384,17 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
         if (nt) LZX_TRY((launch_spmv_t<false, true>(c, a)));
         else    LZX_TRY((launch_spmv_t<false, false>(c, a)));
     }
+    if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[1], c->stream));
     if (c->fin_grid > 0) {
         hipLaunchKernelGGL(k_long_finish, dim3(c->fin_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
                            c->d_item_first, c->d_long_partial, c->n_long64, l.q_loc, l.v,
                            l.partials + c->spmv_grid);
     }
     LZX_HIP(hipGetLastError());
+    if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[2], c->stream));
+    // entries whose column is not staged in LDS: two streaming passes that add into v (lzx_pb.hip)
+    LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, l.partials + c->spmv_grid + c->fin_grid));
+    if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[4], c->stream));
     return LZX_OK;
 }
 

@@ -29,7 +29,7 @@ def test_golden_through_c_abi(pkg, oracle, path):
     O = oracle
     g = np.load(path)
     n, k = int(g["mtx_n"]), int(g["k"])
-    eng = pkg.Engine(0)
+    eng = pkg.Engine(0, propagation_blocking=0)                       # reference summation order for body rows
     eng.set_graph_csr32(g["ref_row_offset"], g["ref_col_idx"])       # parallel-final's `unsigned` arrays
     y = eng.spmv(g["x"])
     deg = np.diff(g["ref_row_offset"].astype(np.int64))

@@ -13,8 +13,14 @@ def rel_inf(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
 
+# engine modes: plain gather path (bit-exact body rows), propagation-blocked path, the same with a tiny hub so that
+# almost every entry goes through the blocked passes
+MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=64)]
+
+
 def graphs(O):
     yield "er_c1", O.gen_er(10000, 100000, 1234)           # BASELINE config C1
+    yield "er_200k", O.gen_er(200000, 1000000, 21)           # 13 column bands x 196 row bands when blocked
     yield "rmat_s14", O.gen_rmat(14, 12000, 200000, 7)       # skewed, n not a power of two, split rows
     yield "er_tiny", O.gen_er(130, 300, 3)
     yield "rmat_hub", O.gen_rmat(16, 65536, 1500000, 99, a=0.7, b=0.12, c=0.12)  # very long rows
@@ -56,11 +62,19 @@ def test_spmv_matches_oracle(oracle, engine_factory):
     rng = np.random.default_rng(1234)
     for name, (rp, ci) in graphs(O):
         n = len(rp) - 1
-        eng = engine_factory()
-        eng.set_graph_csr(rp, ci)
         x = rng.random(n)
-        y = eng.spmv(x)
         y_ref = O.spmv(rp, ci, x)
+        for mode in MODES[1:]:
+            eng = engine_factory(**mode)
+            eng.set_graph_csr(rp, ci)
+            gi = eng.info()
+            assert gi["pb_entries"] > 0 or n <= gi["hub_entries"], (name, mode)
+            assert np.allclose(eng.spmv(x), y_ref, rtol=1e-13, atol=0), (name, mode)
+            eng.close()
+        eng = engine_factory(**MODES[0])
+        eng.set_graph_csr(rp, ci)
+        assert eng.info()["pb_entries"] == 0
+        y = eng.spmv(x)
         # Rows of the sliced-ELL body are summed left to right by one lane, the reference's own order
         # (serial/lib/SPMV.cc:24-27): bit-exact.  The split rows (degree > 1024, rounded up to a whole
         # 64-row slice in degree order) are tree-summed: 1e-13 relative.
@@ -81,20 +95,21 @@ def test_lanczos_matches_oracle(oracle, engine_factory):
         k = min(20, n - 1)
         x0 = np.ones(n)
         a_ref, b_ref, Q_ref, xn_ref, ans_ref = pipeline_ref(O, rp, ci, k, x0)
-        eng = engine_factory()
-        eng.set_graph_csr(rp, ci)
-        a, b, Q, xn, st = eng.lanczos(x0, k)
-        assert xn == xn_ref
-        check_leading_coefficients(a, b, a_ref, b_ref, name)
-        check_recurrence(O, rp, ci, a, b, Q, name)
-        lam, V = O.eigen(a, b)
-        ans_host = O.mult_out(np.ascontiguousarray(Q.T), V, lam, xn)       # host multOut on the GPU basis
-        ans_dev = eng.multout(V @ (np.exp(lam) * (xn * V[0, :])))            # device multOut
-        if np.isfinite(ans_ref).all():
-            assert rel_inf(ans_host, ans_ref) <= REL_INF_TOL, name
-            assert rel_inf(ans_dev, ans_ref) <= REL_INF_TOL, name
-        assert st["iters"] == k and st["loop_ms"] > 0
-        eng.close()
+        for mode in MODES:
+            eng = engine_factory(**mode)
+            eng.set_graph_csr(rp, ci)
+            a, b, Q, xn, st = eng.lanczos(x0, k)
+            assert xn == xn_ref
+            check_leading_coefficients(a, b, a_ref, b_ref, (name, mode))
+            check_recurrence(O, rp, ci, a, b, Q, (name, mode))
+            lam, V = O.eigen(a, b)
+            ans_host = O.mult_out(np.ascontiguousarray(Q.T), V, lam, xn)       # host multOut on the GPU basis
+            ans_dev = eng.multout(V @ (np.exp(lam) * (xn * V[0, :])))            # device multOut
+            if np.isfinite(ans_ref).all():
+                assert rel_inf(ans_host, ans_ref) <= REL_INF_TOL, (name, mode)
+                assert rel_inf(ans_dev, ans_ref) <= REL_INF_TOL, (name, mode)
+            assert st["iters"] == k and st["loop_ms"] > 0
+            eng.close()
 
 
 def test_generators_bit_exact(oracle, engine_factory):
@@ -135,18 +150,19 @@ def test_local_group_matches_single(oracle, pkg):
     n, k = len(rp) - 1, 16
     x0 = np.ones(n)
     a_ref, b_ref, Q_ref, xn_ref, ans_ref = pipeline_ref(O, rp, ci, k, x0)
-    grp = pkg.LocalGroup([0, 0, 0])
-    grp.set_graph_csr(rp, ci)
-    x = np.random.default_rng(5).random(n)
-    assert np.allclose(grp.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
-    a, b, Q, xn, st = grp.lanczos(x0, k)
-    check_leading_coefficients(a, b, a_ref, b_ref, "local3")
-    check_recurrence(O, rp, ci, a, b, Q, "local3")
-    lam, V = O.eigen(a, b)
-    ans = grp.multout(V @ (np.exp(lam) * (xn * V[0, :])))
-    assert rel_inf(ans, ans_ref) <= REL_INF_TOL
-    assert rel_inf(O.mult_out(np.ascontiguousarray(Q.T), V, lam, xn), ans_ref) <= REL_INF_TOL
-    grp.close()
+    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=256)):
+        grp = pkg.LocalGroup([0, 0, 0], **mode)
+        grp.set_graph_csr(rp, ci)
+        x = np.random.default_rng(5).random(n)
+        assert np.allclose(grp.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+        a, b, Q, xn, st = grp.lanczos(x0, k)
+        check_leading_coefficients(a, b, a_ref, b_ref, ("local3", mode))
+        check_recurrence(O, rp, ci, a, b, Q, ("local3", mode))
+        lam, V = O.eigen(a, b)
+        ans = grp.multout(V @ (np.exp(lam) * (xn * V[0, :])))
+        assert rel_inf(ans, ans_ref) <= REL_INF_TOL
+        assert rel_inf(O.mult_out(np.ascontiguousarray(Q.T), V, lam, xn), ans_ref) <= REL_INF_TOL
+        grp.close()
 
 
 def test_rccl_world1(oracle, pkg):
