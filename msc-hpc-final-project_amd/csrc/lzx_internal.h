@@ -42,7 +42,7 @@ void lzx_set_error(const char *fmt, ...);
 // wave reads 16 contiguous bytes (4 indices of ITS row) per step and the wave reads 1 KiB contiguous.
 static constexpr u32 LZX_SLICE = 64;
 // Rows with more entries than this leave the sliced-ELL body and are split into wave-sized items.
-static constexpr u32 LZX_LONG_ROW = 1024;
+static constexpr u32 LZX_LONG_ROW = 128;
 // Entries one wavefront sums per split-row item (multiple of 256 = 64 lanes x 4 indices).
 static constexpr u32 LZX_ITEM = 2048;
 // Threads per workgroup of the SpMV kernel (16 wavefronts share one LDS copy of the hub entries).

@@ -145,6 +145,8 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
     // Software pipeline across slices: while slice s is summed, the first four index packets of the wave's next
     // slice are already in flight (after the hub split most slices are only a few packets wide, so without this
     // every slice pays a full memory round trip on its own).
+    // Units are dealt to wavefronts round-robin: neighbouring wavefronts stream neighbouring memory, and because
+    // slice widths fall monotonically (and are capped by the split-row threshold) every wavefront gets the same work.
     u32 s = w0;
     bool have = s < a.n_slices;
     const uint4 *p = nullptr;

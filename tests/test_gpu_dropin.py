@@ -34,7 +34,7 @@ def test_golden_through_c_abi(pkg, oracle, path):
     y = eng.spmv(g["x"])
     deg = np.diff(g["ref_row_offset"].astype(np.int64))
     order = np.argsort(-deg, kind="stable")
-    n_split = -(-int((deg > 1024).sum()) // 64) * 64
+    n_split = -(-int((deg > 128).sum()) // 64) * 64
     body = np.ones(n, dtype=bool)
     body[order[:n_split]] = False
     assert np.array_equal(y[body], g["ref_spmv"][body])

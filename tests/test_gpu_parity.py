@@ -76,11 +76,11 @@ def test_spmv_matches_oracle(oracle, engine_factory):
         assert eng.info()["pb_entries"] == 0
         y = eng.spmv(x)
         # Rows of the sliced-ELL body are summed left to right by one lane, the reference's own order
-        # (serial/lib/SPMV.cc:24-27): bit-exact.  The split rows (degree > 1024, rounded up to a whole
+        # (serial/lib/SPMV.cc:24-27): bit-exact.  The split rows (degree > 128, rounded up to a whole
         # 64-row slice in degree order) are tree-summed: 1e-13 relative.
         deg = np.diff(rp.astype(np.int64))
         order = np.argsort(-deg, kind="stable")
-        n_split = -(-int((deg > 1024).sum()) // 64) * 64
+        n_split = -(-int((deg > 128).sum()) // 64) * 64
         body = np.ones(n, dtype=bool)
         body[order[:n_split]] = False
         assert np.array_equal(y[body], y_ref[body]), name

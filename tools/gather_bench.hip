@@ -31,7 +31,14 @@ __global__ void fill_idx(uint32_t *idx, uint64_t count, uint32_t table, int skew
     idx[i] = v;
 }
 
-template <int UNROLL>
+template <int MODE> __device__ __forceinline__ double ld(const double *p)
+{
+    if (MODE == 1) return __builtin_nontemporal_load(p);
+    if (MODE == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+template <int UNROLL, int MODE>
 __global__ void __launch_bounds__(1024) gather_k(const uint32_t *idx, uint64_t packets, const double *tab, double *out)
 {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,8 +53,8 @@ __global__ void __launch_bounds__(1024) gather_k(const uint32_t *idx, uint64_t p
         double x[UNROLL * 4];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            x[4 * u + 0] = tab[c[u].x]; x[4 * u + 1] = tab[c[u].y];
-            x[4 * u + 2] = tab[c[u].z]; x[4 * u + 3] = tab[c[u].w];
+            x[4 * u + 0] = ld<MODE>(tab + c[u].x); x[4 * u + 1] = ld<MODE>(tab + c[u].y);
+            x[4 * u + 2] = ld<MODE>(tab + c[u].z); x[4 * u + 3] = ld<MODE>(tab + c[u].w);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL * 4; ++u) acc += x[u];
@@ -90,14 +97,22 @@ int main(int argc, char **argv)
         for (uint64_t t : tables) {
             fill_idx<<<(unsigned)((count + 255) / 256), 256>>>(idx, count, (uint32_t)t, skew);
             CHECK(hipDeviceSynchronize());
-            float best = 1e30f;
-            for (int r = 0; r < 4; ++r) {
-                CHECK(hipEventRecord(a)); gather_k<2><<<grid, 1024>>>(idx, count / 4, tab, out);
-                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
-                float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+            float bestm[3];
+            for (int mode = 0; mode < 3; ++mode) {
+                float best = 1e30f;
+                for (int r = 0; r < 3; ++r) {
+                    CHECK(hipEventRecord(a));
+                    if (mode == 0) gather_k<2, 0><<<grid, 1024>>>(idx, count / 4, tab, out);
+                    if (mode == 1) gather_k<2, 1><<<grid, 1024>>>(idx, count / 4, tab, out);
+                    if (mode == 2) gather_k<2, 2><<<grid, 1024>>>(idx, count / 4, tab, out);
+                    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                    float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+                }
+                bestm[mode] = best;
             }
-            printf("skew=%d table %9.2f MB: %8.3f ms  %7.1f Ggather/s  (index stream %.2f TB/s)\n", skew, t * 8 / 1e6,
-                   best, count / best / 1e6, count * 4 / best / 1e9);
+            const float best = bestm[0];
+            printf("skew=%d table %9.2f MB: %8.3f ms  %7.1f Ggather/s  (index stream %.2f TB/s)  nt %7.1f  sc1 %7.1f Ggather/s\n", skew, t * 8 / 1e6,
+                   best, count / best / 1e6, count * 4 / best / 1e9, count / bestm[1] / 1e6, count / bestm[2] / 1e6);
             fflush(stdout);
         }
     return 0;
