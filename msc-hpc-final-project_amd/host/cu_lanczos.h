@@ -36,6 +36,7 @@ T inner_prod(const T *const v, const T *const w, const U n) {
 
 template <typename T> class eigenDecomp;
 template <typename T> class lanczosDecomp;
+struct convergenceReport;
 template <typename U, typename V> void check_ans(lanczosDecomp<U> &, lanczosDecomp<V> &);
 
 // Timings of the device path of the last constructed decomposition (milliseconds).
@@ -71,6 +72,7 @@ class lanczosDecomp {
   friend class eigenDecomp<T>;
   template <typename U> friend void multOut(lanczosDecomp<U> &, eigenDecomp<U> &, adjMatrix &, bool);
   template <typename U> friend void cu_multOut(lanczosDecomp<U> &, eigenDecomp<U> &, adjMatrix &, bool);
+  template <typename U> friend struct convergenceReport multOutAdaptive(lanczosDecomp<U> &, adjMatrix &, unsigned, double, bool);
   template <typename U, typename V> friend void check_ans(lanczosDecomp<U> &, lanczosDecomp<V> &);
   template <typename U> friend void write_ans(std::string filename, lanczosDecomp<U> &);
 

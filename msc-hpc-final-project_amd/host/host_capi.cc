@@ -87,6 +87,31 @@ long host_gen_csr(char kind, unsigned scale, unsigned n, unsigned long long E, u
   }
 }
 
+// Convergence monitor on a graph file: decomposition of dimension kmax, then multOutAdaptive(step, tol).
+// ks[], changes[] receive up to `cap` evaluated dimensions / relative changes; returns how many, or < 0.
+long host_adaptive_file(const char *path, unsigned kmax, unsigned step, double tol, int cuda, double *ans,
+                        unsigned ans_len, unsigned *ks, double *changes, unsigned cap, unsigned *k_used) {
+  try {
+    std::ifstream fs(path);
+    if (fs.fail()) { g_host_err = std::string("cannot open ") + path; return -1; }
+    unsigned n = 0, edges = 0;
+    fs >> n >> n >> edges;
+    adjMatrix A(n, edges, fs);
+    if (ans_len < n) { g_host_err = "answer buffer too small"; return -2; }
+    std::vector<double> x(n, 1.0);
+    lanczosDecomp<double> L(A, kmax, x.data(), cuda != 0);
+    const convergenceReport rep = multOutAdaptive(L, A, step, tol, cuda != 0);
+    std::copy(L.answer(), L.answer() + n, ans);
+    const unsigned m = std::min<unsigned>(cap, static_cast<unsigned>(rep.k.size()));
+    for (unsigned i = 0; i < m; ++i) { ks[i] = rep.k[i]; changes[i] = rep.rel_change[i]; }
+    *k_used = rep.k_used;
+    return static_cast<long>(rep.k.size());
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
 // Loader only: CSR of a graph file as the adjMatrix file constructor builds it.
 // row_offset[n+1], col_idx[2*E] (caller sizes them from the header); returns stored edges or < 0.
 long host_load_csr(const char *path, unsigned *row_offset, unsigned *col_idx, unsigned max_nnz) {

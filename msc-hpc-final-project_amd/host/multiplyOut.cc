@@ -1,6 +1,8 @@
 #include "multiplyOut.h"
 
+#include <algorithm>
 #include <cmath>
+#include <string>
 #include <stdexcept>
 #include <vector>
 
@@ -57,7 +59,70 @@ void cu_multOut(lanczosDecomp<T> &L, eigenDecomp<T> &E, adjMatrix &, bool) {
   for (std::size_t i = 0; i < out.size(); ++i) L.ans[i] = static_cast<T>(out[i]);
 }
 
+template <typename T>
+convergenceReport multOutAdaptive(lanczosDecomp<T> &L, adjMatrix &, unsigned step, double tol, bool Qtrans) {
+  const std::size_t n = L.get_n();
+  const unsigned K = L.get_krylov();
+  if (step == 0) step = 5;
+  convergenceReport rep;
+  std::vector<double> prev, cur(n), d, e, z, t;
+  for (unsigned k = std::min(step, K);; k = std::min(k + step, K)) {
+    // leading k x k block of T: eigen-decomposition, then t = V (e^lambda .* ||x|| V[0,:])
+    d.assign(L.alpha, L.alpha + k);
+    e.assign(k, 0.0);
+    for (unsigned i = 0; i + 1 < k; ++i) e[i] = L.beta[i];
+    z.assign(static_cast<std::size_t>(k) * k, 0.0);
+    if (symtridiag_ql(static_cast<int>(k), d.data(), e.data(), z.data()) != 0)
+      throw std::runtime_error("multOutAdaptive: QL iteration did not converge");
+    t.assign(k, 0.0);
+    for (unsigned j = 0; j < k; ++j) d[j] = std::exp(d[j]) * (static_cast<double>(L.x_norm) * z[j]);
+    for (unsigned i = 0; i < k; ++i) {
+      double s = 0;
+      for (unsigned j = 0; j < k; ++j) s += z[static_cast<std::size_t>(i) * k + j] * d[j];
+      t[i] = s;
+    }
+    // y_k = Q_k t
+    if (L.on_device()) {
+      if (lzx_multout_f64(L.engine, t.data(), k, cur.data()) != LZX_OK)
+        throw std::runtime_error(std::string("lzx_multout_f64: ") + lzx_last_error());
+    } else if (Qtrans) {
+      std::fill(cur.begin(), cur.end(), 0.0);
+      for (unsigned j = 0; j < k; ++j) {
+        const T *q = L.Q + static_cast<std::size_t>(j) * n;
+        for (std::size_t i = 0; i < n; ++i) cur[i] += t[j] * q[i];
+      }
+    } else {
+      for (std::size_t i = 0; i < n; ++i) {
+        const T *row = L.Q + i * K;
+        double s = 0;
+        for (unsigned j = 0; j < k; ++j) s += row[j] * t[j];
+        cur[i] = s;
+      }
+    }
+    double change = 1.0;
+    if (!prev.empty()) {
+      double d2 = 0, y2 = 0;
+      for (std::size_t i = 0; i < n; ++i) {
+        const double df = cur[i] - prev[i];
+        d2 += df * df;
+        y2 += cur[i] * cur[i];
+      }
+      change = std::sqrt(d2) / std::sqrt(y2);
+    }
+    rep.k.push_back(k);
+    rep.rel_change.push_back(change);
+    rep.k_used = k;
+    prev = cur;
+    if (!(change > tol)) { rep.converged = true; break; }   // also stops on NaN
+    if (k == K) break;
+  }
+  for (std::size_t i = 0; i < n; ++i) L.ans[i] = static_cast<T>(prev[i]);
+  return rep;
+}
+
 template void multOut(lanczosDecomp<double> &, eigenDecomp<double> &, adjMatrix &, bool);
 template void multOut(lanczosDecomp<float> &, eigenDecomp<float> &, adjMatrix &, bool);
 template void cu_multOut(lanczosDecomp<double> &, eigenDecomp<double> &, adjMatrix &, bool);
 template void cu_multOut(lanczosDecomp<float> &, eigenDecomp<float> &, adjMatrix &, bool);
+template convergenceReport multOutAdaptive(lanczosDecomp<double> &, adjMatrix &, unsigned, double, bool);
+template convergenceReport multOutAdaptive(lanczosDecomp<float> &, adjMatrix &, unsigned, double, bool);

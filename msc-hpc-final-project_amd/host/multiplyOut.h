@@ -7,6 +7,8 @@
 #include "cu_lanczos.h"
 #include "eigen.h"
 
+#include <vector>
+
 // Qtrans == true : L.Q holds k contiguous vectors (device decomposition)
 // Qtrans == false: L.Q is row-major n x k          (CPU decomposition)
 template <typename T>
@@ -16,3 +18,18 @@ void multOut(lanczosDecomp<T> &, eigenDecomp<T> &, adjMatrix &, bool Qtrans);
 // k x k part stays on the host.  Requires L to come from cuda == true (and not free_mem'ed).
 template <typename T>
 void cu_multOut(lanczosDecomp<T> &, eigenDecomp<T> &, adjMatrix &, bool Qtrans = true);
+
+// Convergence monitor (the reference's stated open problem, writeup section 11: "multOut for the first k < r
+// columns").  From ONE decomposition of dimension K it evaluates the Krylov approximation
+// y_k = ||x|| Q_k V_k e^{Lambda_k} V_k^T e_1 for k = step, 2*step, ... <= K, each from the leading k x k block of
+// the tridiagonal matrix, and stops at the first k whose answer moved by less than `tol` (relative 2-norm) from
+// the previous one.  L.ans holds y_{k_used} afterwards.  Uses the GPU-resident basis when L has one.
+struct convergenceReport {
+  unsigned k_used = 0;
+  bool converged = false;
+  std::vector<unsigned> k;          // dimensions evaluated
+  std::vector<double> rel_change;   // ||y_k - y_{k-step}|| / ||y_k|| (first entry: 1)
+};
+
+template <typename T>
+convergenceReport multOutAdaptive(lanczosDecomp<T> &L, adjMatrix &A, unsigned step, double tol, bool Qtrans);

@@ -94,3 +94,27 @@ def test_bench_contract_small_workload():
     assert j["steps"] == 20 and j["n_gpus"] == 1 and j["dtype"] == "f64" and j["value"] > 0
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
+
+
+def test_convergence_monitor_device(pkg, tmp_path):
+    """The same monitor on the GPU-resident basis (lzx_multout_f64 with k' <= k)."""
+    pkg.lib()
+    H = ctypes.CDLL(os.path.join(HOST_DIR, "libmschpc_host.so"))
+    _u32p = ctypes.POINTER(ctypes.c_uint32)
+    H.host_adaptive_file.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_double, ctypes.c_int, _f64p,
+                                     ctypes.c_uint, _u32p, _f64p, ctypes.c_uint, _u32p]
+    H.host_adaptive_file.restype = ctypes.c_long
+    H.host_last_error.restype = ctypes.c_char_p
+    g = np.load(GOLDEN[1])
+    n = int(g["mtx_n"])
+    mtx = str(tmp_path / "g.mtx")
+    write_pairs(mtx, n, g["mtx_pairs"])
+    ans = np.zeros(n)
+    ks = np.zeros(16, dtype=np.uint32)
+    ch = np.zeros(16)
+    used = ctypes.c_uint()
+    m = H.host_adaptive_file(mtx.encode(), 40, 5, 1e-12, 1, ans.ctypes.data_as(_f64p), n, ks.ctypes.data_as(_u32p),
+                             ch.ctypes.data_as(_f64p), 16, ctypes.cast(ctypes.byref(used), _u32p))
+    assert m > 2, H.host_last_error()
+    assert ch[m - 1] <= 1e-12 and used.value < 40
+    assert np.abs(ans - g["expm_ref"]).max() <= 1e-10 * np.abs(g["expm_ref"]).max()

@@ -1,0 +1,107 @@
+"""GPU: BASELINE.json's full-size configurations (C2, C3) through size-independent properties, plus the edge
+cases (empty graph, tiny n, k = 1, maximum skew).  The oracle is used only where it finishes in seconds (C2)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def check_properties(eng, n, k, rng, spmv_ref=None):
+    x, y = rng.random(n), rng.random(n)
+    Ax, Ay = eng.spmv(x), eng.spmv(y)
+    if spmv_ref is not None:
+        assert np.allclose(Ax, spmv_ref(x), rtol=1e-13, atol=0)
+    # A is symmetric: x'(Ay) = y'(Ax); and linear: A(2x - 3y) = 2Ax - 3Ay
+    assert abs(x @ Ay - y @ Ax) <= 1e-12 * abs(x @ Ay)
+    assert np.allclose(eng.spmv(2.0 * x - 3.0 * y), 2.0 * Ax - 3.0 * Ay, rtol=1e-12, atol=1e-9)
+    # all-ones vector: row sums = degrees, exactly (integers)
+    rp, _ = eng.get_graph_csr()
+    assert np.array_equal(eng.spmv(np.ones(n)), np.diff(rp.astype(np.int64)).astype(np.float64))
+    # Lanczos: three-term recurrence and unit norms, checked with the device SpMV itself
+    a, b, Q, xn, st = eng.lanczos(np.ones(n), k)
+    assert xn == np.sqrt(float(n))
+    scale = max(np.abs(a).max(), np.abs(b).max())
+    for j in range(k - 1):
+        r = eng.spmv(Q[j]) - a[j] * Q[j] - b[j] * Q[j + 1]
+        if j > 0:
+            r -= b[j - 1] * Q[j - 1]
+        assert np.abs(r).max() <= 1e-12 * scale, j
+        assert abs(np.linalg.norm(Q[j]) - 1.0) <= 1e-13, j
+    # neighbouring Lanczos vectors are orthogonal to rounding (no re-orthogonalisation is claimed beyond that)
+    assert abs(Q[0] @ Q[1]) <= 1e-13
+    # device multOut is linear in t and equals Q^T t
+    t = rng.random(k)
+    assert np.allclose(eng.multout(t), t @ Q, rtol=1e-12, atol=1e-14)
+    return st
+
+
+def test_c2_full_size(pkg, oracle):
+    O = oracle
+    eng = pkg.Engine(0)
+    eng.gen_rmat(20, 1 << 20, 20_000_000, 1234)          # BASELINE C2
+    gi = eng.info()
+    assert gi["n"] == 1 << 20 and 36_000_000 < gi["nnz"] < 40_000_000
+    rp, ci = eng.get_graph_csr()
+    st = check_properties(eng, gi["n"], 8, np.random.default_rng(2), spmv_ref=lambda x: O.spmv(rp, ci, x))
+    assert st["spmv_bytes"] == 4 * gi["nnz"] + 4 * (gi["n"] + 1) + 16 * gi["n"]
+    eng.close()
+
+
+def test_c3_full_size_properties(pkg):
+    eng = pkg.Engine(0)
+    eng.gen_rmat(24, 10_000_000, 200_000_000, 1234)       # BASELINE C3 / C4 graph
+    gi = eng.info()
+    assert gi["n"] == 10_000_000 and 380_000_000 < gi["nnz"] < 400_000_000
+    check_properties(eng, gi["n"], 5, np.random.default_rng(3))
+    eng.close()
+
+
+def test_edge_cases(pkg, oracle):
+    O = oracle
+    # no edges at all: A = 0 -> v = 0, alpha = 0; beta_0 = 0 makes q_1 = 0/0 as in the reference (no guard)
+    eng = pkg.Engine(0)
+    eng.set_graph_csr(np.zeros(101, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+    assert np.array_equal(eng.spmv(np.ones(100)), np.zeros(100))
+    a, b, Q, xn, _ = eng.lanczos(np.ones(100), 1)
+    assert a[0] == 0.0 and xn == 10.0 and np.allclose(Q[0], 0.1)
+    a, b, Q, xn, _ = eng.lanczos(np.ones(100), 3)
+    assert a[0] == 0.0 and b[0] == 0.0 and not np.isfinite(a[1])
+    eng.close()
+    # a single edge, n = 2; k = 1
+    eng = pkg.Engine(0)
+    eng.set_graph_csr(np.array([0, 1, 2], dtype=np.uint64), np.array([1, 0], dtype=np.uint32))
+    assert np.array_equal(eng.spmv(np.array([3.0, 5.0])), np.array([5.0, 3.0]))
+    a, b, Q, xn, _ = eng.lanczos(np.ones(2), 1)
+    assert abs(a[0] - 1.0) <= 1e-15
+    eng.close()
+    # maximum skew: a star (hub of degree n - 1) -- exercises the split-row path with a single row
+    n = 70001
+    src = np.zeros(n - 1, dtype=np.uint32)
+    dst = np.arange(1, n, dtype=np.uint32)
+    eng = pkg.Engine(0)
+    eng.set_graph_edges(n, src, dst)
+    x = np.random.default_rng(4).random(n)
+    y = eng.spmv(x)
+    assert np.isclose(y[0], x[1:].sum(), rtol=1e-13) and np.array_equal(y[1:], np.full(n - 1, x[0]))
+    a, b, Q, xn, _ = eng.lanczos(np.ones(n), 4)
+    # closed form for the star: alpha_0 = 2(n-1)/n, beta_0^2 = ((n-1-alpha_0)^2 + (n-1)(1-alpha_0)^2)/n.  (The
+    # oracle's left-to-right sums over 70 001 terms are themselves ~1e-12 off here; the tree sums are not.)
+    from fractions import Fraction
+    al = Fraction(2 * (n - 1), n)
+    be2 = ((n - 1 - al) ** 2 + (n - 1) * (1 - al) ** 2) / n
+    assert abs(a[0] - float(al)) <= 1e-14 * float(al)
+    assert abs(b[0] - float(be2) ** 0.5) <= 1e-13 * float(be2) ** 0.5
+    rp, ci = eng.get_graph_csr()
+    a_ref, b_ref, _, _ = O.lanczos(rp, ci, 4, np.ones(n))
+    assert abs(a[0] - a_ref[0]) <= 1e-11 * abs(a_ref[0]) and abs(b[0] - b_ref[0]) <= 1e-10 * b_ref[0]
+    eng.close()
+    # arguments
+    eng = pkg.Engine(0)
+    with pytest.raises(pkg.LzxError):
+        eng.lanczos_run()                                   # no graph yet
+    eng.set_graph_csr(np.array([0, 1, 2], dtype=np.uint64), np.array([1, 0], dtype=np.uint32))
+    with pytest.raises(pkg.LzxError):
+        eng.multout(np.ones(2))                             # no decomposition yet
+    with pytest.raises(pkg.LzxError):
+        eng.set_option("hub_entries", 4)                    # options are fixed once the graph is in
+    eng.close()

@@ -24,6 +24,9 @@ def host(pkg):
     H.host_expm_file.restype = ctypes.c_long
     H.host_load_csr.argtypes = [ctypes.c_char_p, _u32p, _u32p, ctypes.c_uint]
     H.host_load_csr.restype = ctypes.c_long
+    H.host_adaptive_file.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_double, ctypes.c_int, _f64p,
+                                     ctypes.c_uint, _u32p, _f64p, ctypes.c_uint, _u32p]
+    H.host_adaptive_file.restype = ctypes.c_long
     H.host_gen_csr.argtypes = [ctypes.c_char, ctypes.c_uint, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_ulonglong, _u32p, _u32p, ctypes.c_uint]
     H.host_gen_csr.restype = ctypes.c_long
     return H
@@ -103,3 +106,23 @@ def test_missing_file_reports_error(host):
     ans = np.zeros(4)
     assert host.host_expm_file(b"/nonexistent/graph.mtx", 3, 0, 0, p(ans, _f64p), 4, None, None) == -1
     assert b"cannot open" in host.host_last_error()
+
+
+def test_convergence_monitor_cpu(host, tmp_path):
+    """multOutAdaptive: the change between successive Krylov dimensions falls monotonically to the tolerance and the
+    answer at the stopping dimension matches the fixture (reference's open problem, writeup section 11)."""
+    g = np.load(GOLDEN[1])
+    n = int(g["mtx_n"])
+    mtx = str(tmp_path / "g.mtx")
+    write_pairs(mtx, n, g["mtx_pairs"])
+    ans = np.zeros(n)
+    ks = np.zeros(16, dtype=np.uint32)
+    ch = np.zeros(16)
+    used = ctypes.c_uint()
+    m = host.host_adaptive_file(mtx.encode(), 40, 5, 1e-12, 0, p(ans, _f64p), n, p(ks, _u32p), p(ch, _f64p), 16,
+                                ctypes.cast(ctypes.byref(used), _u32p))
+    assert m > 2, host.host_last_error()
+    assert list(ks[:m]) == [5 * (i + 1) for i in range(m)]
+    assert ch[0] == 1.0 and np.all(np.diff(ch[1:m]) < 0) and ch[m - 1] <= 1e-12
+    assert used.value == ks[m - 1] and used.value < 40          # stopped early
+    assert np.abs(ans - g["expm_ref"]).max() <= 1e-10 * np.abs(g["expm_ref"]).max()
