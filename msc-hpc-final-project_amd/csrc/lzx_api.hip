@@ -85,6 +85,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
     else if (!strcmp(name, "pb_debug")) c->pb_debug = value;
     else if (!strcmp(name, "pb_target")) c->pb_target_opt = value;
+    else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;

@@ -55,7 +55,8 @@ static constexpr u32 LZX_TAIL = 64;
 static constexpr u32 LZX_PB_CB = 16384;
 static constexpr u32 LZX_PB_RB = 1024;
 static constexpr u32 LZX_PB_UNIT = 1u << 18;
-static constexpr u32 LZX_PB_TARGET = 16384;   // entries per row band = per gather wavefront
+static constexpr u32 LZX_PB_TARGET = 32768;   // entries per row band = per gather wavefront
+static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
 
 struct lzx_ctx {
@@ -92,6 +93,7 @@ struct lzx_ctx {
     int64_t nt_opt = -1;
     int64_t pb_opt = -1;               // propagation blocking: -1 auto, 0 off, 1 on
     int64_t pb_target_opt = -1;        // entries per row band override
+    int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
     int64_t pb_debug = 0;              // ablation switches (tools/perf_probe.py): low 4 bits scatter, next 4 gather
     int64_t long_row_opt = -1;         // split-row threshold override
     int64_t phase_mask_opt = 3;        // debug: 1 = split rows only, 2 = body only
@@ -122,10 +124,11 @@ struct lzx_ctx {
     u32 pb_units = 0;                  // scatter work units
     uint16_t *d_pb_lcol = nullptr;     // [pb_entries] scatter order: column within its band
     u32 *d_pb_dst = nullptr;           // [pb_entries] scatter order: slot in d_pb_val (gather order)
-    uint16_t *d_pb_lrow = nullptr;     // [pb_entries] gather order: row within its band
+    uint16_t *d_pb_lrow = nullptr;     // [pb_entries] gather order: slot in the band's y tile (row * rep + replica)
     double *d_pb_val = nullptr;        // [pb_entries] gathered x values in gather order (scratch)
     u32 *d_pb_unit = nullptr;          // [pb_units][3] band, begin, end (scatter order)
     u32 *d_pb_row0 = nullptr;          // [pb_nr + 1] first local row of each row band
+    u32 *d_pb_rep = nullptr;           // [pb_nr] LDS slots per row in that band's y tile
     u32 *d_pb_items = nullptr;         // [pb_n_items][4] row band, begin, end (gather order), slot or ~0
     u32 *d_pb_multi = nullptr;         // [pb_n_multi][3] row, first slot, slots: rows cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows

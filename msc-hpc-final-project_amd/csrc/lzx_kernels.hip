@@ -142,53 +142,49 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
     //      entries one at a time in the caller's column order: the same left-to-right sum as the
     //      reference's spMV (serial/lib/SPMV.cc:24-27), so these rows come out bit-identical to it.
     double dot = 0.0;
-    // Software pipeline across slices: while slice s is summed, the first four index packets of the wave's next
-    // slice are already in flight (after the hub split most slices are only a few packets wide, so without this
-    // every slice pays a full memory round trip on its own).
+    // Software pipeline across slices, two slices wide: while the pair (s, s + waves) is summed, the first four
+    // index packets of the wave's next pair are already in flight.  After the hub split most slices are only a few
+    // packets wide; without this every slice would pay a full memory round trip on its own.
     // Units are dealt to wavefronts round-robin: neighbouring wavefronts stream neighbouring memory, and because
     // slice widths fall monotonically (and are capped by the split-row threshold) every wavefront gets the same work.
-    u32 s = w0;
-    bool have = s < a.n_slices;
-    const uint4 *p = nullptr;
-    u32 steps = 0;
-    uint4 pf[4] = {};
-    if (have) {
-        p = reinterpret_cast<const uint4 *>(a.sell_cols + a.slice_off[s]) + lane;
-        steps = a.slice_w[s] >> 2;
+    struct Slice {
+        const uint4 *p;
+        u32 steps;
+        u32 row;
+        uint4 pf[4];
+    };
+    auto fetch = [&](u32 s, Slice &sl) {
+        sl.steps = 0;
+        sl.p = nullptr;
+        sl.row = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if ((u32)u < steps) pf[u] = load_idx4<NT>(p + (size_t)u * 64);
-    }
-    while (have) {
-        const u32 s2 = s + waves;
-        const bool have2 = s2 < a.n_slices;
-        const uint4 *p2 = nullptr;
-        u32 steps2 = 0;
-        uint4 nf[4] = {};
-        if (have2) {
-            p2 = reinterpret_cast<const uint4 *>(a.sell_cols + a.slice_off[s2]) + lane;
-            steps2 = a.slice_w[s2] >> 2;
+        for (int u = 0; u < 4; ++u) sl.pf[u] = make_uint4(0, 0, 0, 0);
+        if (s < a.n_slices) {
+            sl.p = reinterpret_cast<const uint4 *>(a.sell_cols + a.slice_off[s]) + lane;
+            sl.steps = a.slice_w[s] >> 2;
+            sl.row = a.row0 + s * 64 + lane;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if ((u32)u < steps2) nf[u] = load_idx4<NT>(p2 + (size_t)u * 64);
+                if ((u32)u < sl.steps) sl.pf[u] = load_idx4<NT>(sl.p + (size_t)u * 64);
         }
-
+    };
+    auto sum = [&](const Slice &sl) -> double {
         double acc = 0.0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if ((u32)u < steps) {
-                const double x0 = gather<HUB>(pf[u].x, a.x, hubv, a.hub);
-                const double x1 = gather<HUB>(pf[u].y, a.x, hubv, a.hub);
-                const double x2 = gather<HUB>(pf[u].z, a.x, hubv, a.hub);
-                const double x3 = gather<HUB>(pf[u].w, a.x, hubv, a.hub);
+            if ((u32)u < sl.steps) {
+                const double x0 = gather<HUB>(sl.pf[u].x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(sl.pf[u].y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(sl.pf[u].z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(sl.pf[u].w, a.x, hubv, a.hub);
                 acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
             }
         }
         u32 i = 4;
-        for (; i + 4 <= steps; i += 4) {
+        for (; i + 4 <= sl.steps; i += 4) {
             uint4 c[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(p + (size_t)(i + u) * 64);
+            for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(sl.p + (size_t)(i + u) * 64);
             double xv[16];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -200,24 +196,36 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc += xv[u];
         }
-        for (; i < steps; ++i) {
-            const uint4 c0 = load_idx4<NT>(p + (size_t)i * 64);
+        for (; i < sl.steps; ++i) {
+            const uint4 c0 = load_idx4<NT>(sl.p + (size_t)i * 64);
             const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
             const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
             const double x2 = gather<HUB>(c0.z, a.x, hubv, a.hub);
             const double x3 = gather<HUB>(c0.w, a.x, hubv, a.hub);
             acc += x0; acc += x1; acc += x2; acc += x3;
         }
-        const u32 row = a.row0 + s * 64 + lane;
-        a.v[row] = acc;
-        dot += acc * a.q_loc[row];
+        return acc;
+    };
 
+    Slice curA, curB, nxtA, nxtB;
+    u32 s = w0;
+    fetch(s, curA);
+    fetch(s + waves, curB);
+    while (s < a.n_slices) {
+        const u32 s2 = s + 2 * waves;
+        fetch(s2, nxtA);
+        fetch(s2 + waves, nxtB);
+        const double accA = sum(curA);
+        a.v[curA.row] = accA;
+        dot += accA * a.q_loc[curA.row];
+        if (s + waves < a.n_slices) {
+            const double accB = sum(curB);
+            a.v[curB.row] = accB;
+            dot += accB * a.q_loc[curB.row];
+        }
         s = s2;
-        have = have2;
-        p = p2;
-        steps = steps2;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pf[u] = nf[u];
+        curA = nxtA;
+        curB = nxtB;
     }
 
     dot = wave_sum(dot);
