@@ -427,7 +427,8 @@ int lzx_graph_prepare(lzx_ctx *c)
     // there is work for.
     // 4 workgroups per CU: two are resident at the default 64 KiB of staged x, the rest queue behind them, which evens
     // out the tail (measured: C3 2.16 -> 2.15 ms, C2 0.141 -> 0.133 ms against exactly-resident grids).
-    u32 per_cu = 4;
+    // In propagation-blocking mode the kernel stages 128 KiB per workgroup and only one is resident: one per CU.
+    u32 per_cu = pb ? 1 : 4;
     if (c->wgs_per_cu_opt > 0) per_cu = (u32)c->wgs_per_cu_opt;
     const u32 units = c->n_slices + c->n_items;
     const u32 waves_per_wg = LZX_SPMV_BLOCK / 64;

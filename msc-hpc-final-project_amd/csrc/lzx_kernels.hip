@@ -106,126 +106,180 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
     const u32 waves = gridDim.x * (LZX_SPMV_BLOCK / 64);
     const u32 w0 = blockIdx.x * (LZX_SPMV_BLOCK / 64) + wv;
 
+    // Both loops below are three-stage software pipelines over the wavefront's units (unit i = w0 + i * waves):
+    // while unit i is summed, the index packets of unit i+1 are in flight and the descriptor of unit i+2 is being
+    // fetched.  Without it every unit pays two dependent memory round trips (descriptor, then packets) and, after
+    // the hub split leaves most units only a few packets long, the kernel is bound by those latencies, not by
+    // bandwidth (measured: 0.25 ms for 0.63 GB of indices on the 10 M-vertex graph).
+    // Units are dealt to wavefronts round-robin: neighbouring wavefronts stream neighbouring memory, and because
+    // widths fall monotonically (and are capped by the split-row threshold) every wavefront gets the same work.
+
     // ---- split rows: one wavefront sums one item of <= LZX_ITEM entries, lanes striding 16-byte index
     //      packets; the item totals are combined in row order by k_long_finish.
-    for (u32 it = w0; it < a.n_items; it += waves) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + a.item_beg[it]);
-        const u32 packets = a.item_len[it] >> 2;
-        double acc = 0.0;
-        u32 q = lane;
-        for (; q + 64 < packets; q += 128) {
-            const uint4 c = load_idx4<NT>(p + q), e = load_idx4<NT>(p + q + 64);
-            const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
-            const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
-            const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
-            const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
-            const double x4 = gather<HUB>(e.x, a.x, hubv, a.hub);
-            const double x5 = gather<HUB>(e.y, a.x, hubv, a.hub);
-            const double x6 = gather<HUB>(e.z, a.x, hubv, a.hub);
-            const double x7 = gather<HUB>(e.w, a.x, hubv, a.hub);
-            acc += x0; acc += x1; acc += x2; acc += x3;
-            acc += x4; acc += x5; acc += x6; acc += x7;
+    {
+        u32 it = w0;
+        bool h0 = it < a.n_items, h1 = it + waves < a.n_items;
+        u64 beg0 = 0, beg1 = 0;
+        u32 len0 = 0, len1 = 0;
+        if (h0) { beg0 = a.item_beg[it]; len0 = a.item_len[it]; }
+        if (h1) { beg1 = a.item_beg[it + waves]; len1 = a.item_len[it + waves]; }
+        uint4 pk0 = make_uint4(0, 0, 0, 0), pk1 = make_uint4(0, 0, 0, 0);
+        if (h0) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + beg0);
+            const u32 packets = len0 >> 2;
+            if (lane < packets) pk0 = load_idx4<NT>(p + lane);
+            if (lane + 64 < packets) pk1 = load_idx4<NT>(p + lane + 64);
         }
-        for (; q < packets; q += 64) {
-            const uint4 c = load_idx4<NT>(p + q);
-            const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
-            const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
-            const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
-            const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
-            acc += x0; acc += x1; acc += x2; acc += x3;
+        while (h0) {
+            // stage A: descriptor of item i+2
+            const bool h2 = it + 2 * waves < a.n_items;
+            u64 beg2 = 0;
+            u32 len2 = 0;
+            if (h2) { beg2 = a.item_beg[it + 2 * waves]; len2 = a.item_len[it + 2 * waves]; }
+            // stage B: first two packets per lane of item i+1
+            uint4 nk0 = make_uint4(0, 0, 0, 0), nk1 = make_uint4(0, 0, 0, 0);
+            if (h1) {
+                const uint4 *pn = reinterpret_cast<const uint4 *>(a.long_cols + beg1);
+                const u32 pkn = len1 >> 2;
+                if (lane < pkn) nk0 = load_idx4<NT>(pn + lane);
+                if (lane + 64 < pkn) nk1 = load_idx4<NT>(pn + lane + 64);
+            }
+            // stage C: sum item i
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + beg0);
+            const u32 packets = len0 >> 2;
+            double acc = 0.0;
+            if (lane < packets) {
+                const double x0 = gather<HUB>(pk0.x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(pk0.y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(pk0.z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(pk0.w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            }
+            if (lane + 64 < packets) {
+                const double x0 = gather<HUB>(pk1.x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(pk1.y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(pk1.z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(pk1.w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            }
+            u32 q = lane + 128;
+            for (; q + 64 < packets; q += 128) {
+                const uint4 c = load_idx4<NT>(p + q), e = load_idx4<NT>(p + q + 64);
+                const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
+                const double x4 = gather<HUB>(e.x, a.x, hubv, a.hub);
+                const double x5 = gather<HUB>(e.y, a.x, hubv, a.hub);
+                const double x6 = gather<HUB>(e.z, a.x, hubv, a.hub);
+                const double x7 = gather<HUB>(e.w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;
+                acc += x4; acc += x5; acc += x6; acc += x7;
+            }
+            for (; q < packets; q += 64) {
+                const uint4 c = load_idx4<NT>(p + q);
+                const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) a.long_partial[it] = acc;
+            // rotate
+            it += waves;
+            h0 = h1; h1 = h2;
+            beg0 = beg1; len0 = len1;
+            beg1 = beg2; len1 = len2;
+            pk0 = nk0; pk1 = nk1;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) a.long_partial[it] = acc;
     }
 
     // ---- sliced-ELL body: one wavefront per slice of 64 rows, lane = row.  Each lane adds its row's
     //      entries one at a time in the caller's column order: the same left-to-right sum as the
     //      reference's spMV (serial/lib/SPMV.cc:24-27), so these rows come out bit-identical to it.
     double dot = 0.0;
-    // Software pipeline across slices, two slices wide: while the pair (s, s + waves) is summed, the first four
-    // index packets of the wave's next pair are already in flight.  After the hub split most slices are only a few
-    // packets wide; without this every slice would pay a full memory round trip on its own.
-    // Units are dealt to wavefronts round-robin: neighbouring wavefronts stream neighbouring memory, and because
-    // slice widths fall monotonically (and are capped by the split-row threshold) every wavefront gets the same work.
-    struct Slice {
-        const uint4 *p;
-        u32 steps;
-        u32 row;
+    {
+        u32 s = w0;
+        bool h0 = s < a.n_slices, h1 = s + waves < a.n_slices;
+        u64 off0 = 0, off1 = 0;
+        u32 st0 = 0, st1 = 0;   // packets per lane
+        if (h0) { off0 = a.slice_off[s]; st0 = a.slice_w[s] >> 2; }
+        if (h1) { off1 = a.slice_off[s + waves]; st1 = a.slice_w[s + waves] >> 2; }
         uint4 pf[4];
-    };
-    auto fetch = [&](u32 s, Slice &sl) {
-        sl.steps = 0;
-        sl.p = nullptr;
-        sl.row = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) sl.pf[u] = make_uint4(0, 0, 0, 0);
-        if (s < a.n_slices) {
-            sl.p = reinterpret_cast<const uint4 *>(a.sell_cols + a.slice_off[s]) + lane;
-            sl.steps = a.slice_w[s] >> 2;
-            sl.row = a.row0 + s * 64 + lane;
+        for (int u = 0; u < 4; ++u) pf[u] = make_uint4(0, 0, 0, 0);
+        if (h0) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + off0) + lane;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if ((u32)u < sl.steps) sl.pf[u] = load_idx4<NT>(sl.p + (size_t)u * 64);
+                if ((u32)u < st0) pf[u] = load_idx4<NT>(p + (size_t)u * 64);
         }
-    };
-    auto sum = [&](const Slice &sl) -> double {
-        double acc = 0.0;
+        while (h0) {
+            // stage A: descriptor of slice i+2
+            const bool h2 = s + 2 * waves < a.n_slices;
+            u64 off2 = 0;
+            u32 st2 = 0;
+            if (h2) { off2 = a.slice_off[s + 2 * waves]; st2 = a.slice_w[s + 2 * waves] >> 2; }
+            // stage B: first four packets of slice i+1
+            uint4 nf[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if ((u32)u < sl.steps) {
-                const double x0 = gather<HUB>(sl.pf[u].x, a.x, hubv, a.hub);
-                const double x1 = gather<HUB>(sl.pf[u].y, a.x, hubv, a.hub);
-                const double x2 = gather<HUB>(sl.pf[u].z, a.x, hubv, a.hub);
-                const double x3 = gather<HUB>(sl.pf[u].w, a.x, hubv, a.hub);
-                acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
+            for (int u = 0; u < 4; ++u) nf[u] = make_uint4(0, 0, 0, 0);
+            if (h1) {
+                const uint4 *pn = reinterpret_cast<const uint4 *>(a.sell_cols + off1) + lane;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((u32)u < st1) nf[u] = load_idx4<NT>(pn + (size_t)u * 64);
             }
-        }
-        u32 i = 4;
-        for (; i + 4 <= sl.steps; i += 4) {
-            uint4 c[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(sl.p + (size_t)(i + u) * 64);
-            double xv[16];
+            // stage C: sum slice i
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + off0) + lane;
+            const u32 row = a.row0 + s * 64 + lane;
+            const double qrow = a.q_loc[row];
+            double acc = 0.0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                xv[4 * u + 0] = gather<HUB>(c[u].x, a.x, hubv, a.hub);
-                xv[4 * u + 1] = gather<HUB>(c[u].y, a.x, hubv, a.hub);
-                xv[4 * u + 2] = gather<HUB>(c[u].z, a.x, hubv, a.hub);
-                xv[4 * u + 3] = gather<HUB>(c[u].w, a.x, hubv, a.hub);
+                if ((u32)u < st0) {
+                    const double x0 = gather<HUB>(pf[u].x, a.x, hubv, a.hub);
+                    const double x1 = gather<HUB>(pf[u].y, a.x, hubv, a.hub);
+                    const double x2 = gather<HUB>(pf[u].z, a.x, hubv, a.hub);
+                    const double x3 = gather<HUB>(pf[u].w, a.x, hubv, a.hub);
+                    acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
+                }
             }
+            u32 i = 4;
+            for (; i + 4 <= st0; i += 4) {
+                uint4 c[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc += xv[u];
+                for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(p + (size_t)(i + u) * 64);
+                double xv[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[4 * u + 0] = gather<HUB>(c[u].x, a.x, hubv, a.hub);
+                    xv[4 * u + 1] = gather<HUB>(c[u].y, a.x, hubv, a.hub);
+                    xv[4 * u + 2] = gather<HUB>(c[u].z, a.x, hubv, a.hub);
+                    xv[4 * u + 3] = gather<HUB>(c[u].w, a.x, hubv, a.hub);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += xv[u];
+            }
+            for (; i < st0; ++i) {
+                const uint4 c0 = load_idx4<NT>(p + (size_t)i * 64);
+                const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(c0.z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(c0.w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            }
+            a.v[row] = acc;
+            dot += acc * qrow;
+            // rotate
+            s += waves;
+            h0 = h1; h1 = h2;
+            off0 = off1; st0 = st1;
+            off1 = off2; st1 = st2;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pf[u] = nf[u];
         }
-        for (; i < sl.steps; ++i) {
-            const uint4 c0 = load_idx4<NT>(sl.p + (size_t)i * 64);
-            const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
-            const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
-            const double x2 = gather<HUB>(c0.z, a.x, hubv, a.hub);
-            const double x3 = gather<HUB>(c0.w, a.x, hubv, a.hub);
-            acc += x0; acc += x1; acc += x2; acc += x3;
-        }
-        return acc;
-    };
-
-    Slice curA, curB, nxtA, nxtB;
-    u32 s = w0;
-    fetch(s, curA);
-    fetch(s + waves, curB);
-    while (s < a.n_slices) {
-        const u32 s2 = s + 2 * waves;
-        fetch(s2, nxtA);
-        fetch(s2 + waves, nxtB);
-        const double accA = sum(curA);
-        a.v[curA.row] = accA;
-        dot += accA * a.q_loc[curA.row];
-        if (s + waves < a.n_slices) {
-            const double accB = sum(curB);
-            a.v[curB.row] = accB;
-            dot += accB * a.q_loc[curB.row];
-        }
-        s = s2;
-        curA = nxtA;
-        curB = nxtB;
     }
 
     dot = wave_sum(dot);
