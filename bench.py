@@ -86,7 +86,8 @@ def main():
 
     import torch  # device plumbing + torch.distributed only
     dist = None
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run, also at N = 1
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -97,7 +98,7 @@ def main():
     K, W = args.steps, args.warmup
 
     eng = pkg.Engine(local_rank)
-    if world > 1:
+    if dist is not None:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.from_numpy(pkg.Engine.unique_id()))

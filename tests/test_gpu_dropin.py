@@ -118,3 +118,20 @@ def test_convergence_monitor_device(pkg, tmp_path):
     assert m > 2, H.host_last_error()
     assert ch[m - 1] <= 1e-12 and used.value < 40
     assert np.abs(ans - g["expm_ref"]).max() <= 1e-10 * np.abs(g["expm_ref"]).max()
+
+
+def test_bench_under_torchrun_one_rank():
+    """The launch line the driver uses for N > 1, at N = 1: torch.distributed (nccl) rendezvous, communicator id
+    broadcast, lzx_comm_init_rank over the RCCL copy PyTorch already loaded, barrier / max plumbing."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c1",
+           "--steps", "10", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["steps"] == 10 and j["value"] > 0
