@@ -232,9 +232,11 @@ int lzx_graph_prepare(lzx_ctx *c)
 
     // Propagation blocking (lzx_pb.hip) for every entry whose column is not staged in LDS: worth its two extra
     // launches once x no longer sits in the L2s.  -1 = decide here.
-    // Measured: ahead of the plain gather once x no longer fits the caches (C3: 1.69 vs 2.15 ms),
-    // behind it while x does (C2, 8 MB: 0.24 vs 0.13 ms).  -1 = decide here.
-    bool pb = c->pb_opt > 0 || (c->pb_opt < 0 && n >= (4u << 20) && c->nnz / (u64)world >= (16u << 20));
+    // Measured: ahead of the plain gather once x no longer fits the caches (C3: 1.65 vs 2.14 ms),
+    // behind it while x does (C2, 8 MB: 0.24 vs 0.13 ms); its fixed costs (one x band per scatter workgroup, fewer row
+    // bands than wavefronts) eat the gain when a rank's share is small (tools/rank_probe.py, C3 per-rank SpMV, plain /
+    // blocked: P=2 1.10 / 0.95, P=4 0.59 / 0.55, P=8 0.305 / 0.327 ms).  -1 = decide here.
+    bool pb = c->pb_opt > 0 || (c->pb_opt < 0 && n >= (4u << 20) && c->nnz / (u64)world >= (64u << 20));
     // hub entries staged in LDS by k_spmv: 8192 (64 KiB, two workgroups per CU) when k_spmv also gathers from
     // memory; 16384 (128 KiB, one per CU) in propagation-blocking mode, where it only ever reads LDS.
     u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : (pb ? 16384 : 8192);
