@@ -83,7 +83,6 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "nt_index_loads")) c->nt_opt = value;
     else if (!strcmp(name, "long_row")) c->long_row_opt = value;
     else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
-    else if (!strcmp(name, "pb_debug")) c->pb_debug = value;
     else if (!strcmp(name, "pb_target")) c->pb_target_opt = value;
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;

@@ -94,7 +94,6 @@ struct lzx_ctx {
     int64_t pb_opt = -1;               // propagation blocking: -1 auto, 0 off, 1 on
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
-    int64_t pb_debug = 0;              // ablation switches (tools/perf_probe.py): low 4 bits scatter, next 4 gather
     int64_t long_row_opt = -1;         // split-row threshold override
     int64_t phase_mask_opt = 3;        // debug: 1 = split rows only, 2 = body only
 

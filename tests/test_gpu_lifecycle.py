@@ -1,0 +1,63 @@
+"""GPU: handle lifecycle and reproducibility through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_runs_are_reproducible_bit_for_bit(pkg, oracle):
+    """Fixed-shape reductions, no global atomics: the same handle, a fresh handle and a repeated run agree bit for bit
+    (plain mode by construction; blocked mode as observed -- see DESIGN.md section 3)."""
+    O = oracle
+    rp, ci = O.gen_rmat(16, 50000, 600000, 11)
+    n = len(rp) - 1
+    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=512)):
+        e1 = pkg.Engine(0, **mode)
+        e1.set_graph_csr(rp, ci)
+        a1, b1, Q1, _, _ = e1.lanczos(np.ones(n), 15)
+        a2, b2, Q2, _, _ = e1.lanczos(np.ones(n), 15)
+        e2 = pkg.Engine(0, **mode)
+        e2.set_graph_csr(rp, ci)
+        a3, b3, Q3, _, _ = e2.lanczos(np.ones(n), 15)
+        for a, b, Q in ((a2, b2, Q2), (a3, b3, Q3)):
+            assert np.array_equal(a1, a) and np.array_equal(b1, b) and np.array_equal(Q1, Q), mode
+        e1.close()
+        e2.close()
+
+
+def test_handle_reuse_and_growth(pkg, oracle):
+    O = oracle
+    rp, ci = O.gen_er(3000, 20000, 5)
+    rp2, ci2 = O.gen_er(1200, 9000, 6)
+    eng = pkg.Engine(0)
+    eng.set_graph_csr(rp, ci)
+    a5, b5, _, _, _ = eng.lanczos(np.ones(3000), 5)
+    a30, b30, Q30, xn, _ = eng.lanczos(np.ones(3000), 30)       # the resident basis grows
+    assert np.array_equal(a30[:5], a5) and np.array_equal(b30[:4], b5)   # a longer run extends a shorter one
+    t = np.random.default_rng(0).random(12)
+    assert np.allclose(eng.multout(t), t @ Q30[:12], rtol=1e-12, atol=1e-14)   # multOut on a prefix of the basis
+    eng.set_graph_csr(rp2, ci2)                                  # replace the graph on a live handle
+    with pytest.raises(pkg.LzxError):
+        eng.multout(t)                                           # the old basis is gone
+    x = np.random.default_rng(1).random(1200)
+    assert np.array_equal(eng.spmv(x), O.spmv(rp2, ci2, x))
+    other = pkg.Engine(0)                                        # two live handles on one GPU
+    other.set_graph_csr(rp, ci)
+    y = np.random.default_rng(2).random(3000)
+    assert np.array_equal(other.spmv(y), O.spmv(rp, ci, y))
+    assert np.array_equal(eng.spmv(x), O.spmv(rp2, ci2, x))
+    other.close()
+    eng.close()
+
+
+def test_csr_validation(pkg):
+    eng = pkg.Engine(0)
+    with pytest.raises(pkg.LzxError):
+        eng.set_graph_csr(np.array([0, 1, 3], dtype=np.uint64), np.array([1, 0], dtype=np.uint32))   # row_ptr[n] != nnz
+    with pytest.raises(pkg.LzxError):
+        eng.set_graph_csr(np.array([1, 1, 2], dtype=np.uint64), np.array([1, 0], dtype=np.uint32))   # row_ptr[0] != 0
+    with pytest.raises(pkg.LzxError):
+        eng.set_option("no_such_option", 1)
+    with pytest.raises(pkg.LzxError):
+        pkg.Engine(99)                                            # no such device
+    eng.close()

@@ -41,7 +41,8 @@ if __name__ == "__main__":
     if "pbx" in sets:
         opts = [dict(propagation_blocking=1, hub_entries=h) for h in (4096, 8192, 12288, 16384, 17000, 19000)]
     if "pbdbg" in sets:
-        opts = [dict(), dict(pb_debug=2), dict(wgs_per_cu=1), dict(wgs_per_cu=2), dict(wgs_per_cu=1, pb_debug=2), dict(phase_mask=1), dict(phase_mask=2)]
+        opts = [dict(), dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, pb_target=16384),
+                dict(propagation_blocking=1, pb_run_align=4), dict(propagation_blocking=1, pb_run_align=16)]
     if "pb" in sets:
         opts = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=8192),
                 dict(propagation_blocking=1, hub_entries=19000)]
