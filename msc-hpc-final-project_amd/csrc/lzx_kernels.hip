@@ -8,10 +8,11 @@
 //   k_axpy_norm   alpha_j = sum(partials); v -= alpha_j q_j; v -= beta_{j-1} q_{j-1};
 //                 per-workgroup partials of ||v||^2                (cu_reduce + 2x cu_dpax + cu_norm_sq)
 //   k_scale       beta_j = sqrt(sum(partials)); q_{j+1} = v / beta_j          (cu_reduce_sqrt + cu_dvexda)
-// (+ k_long_finish when the graph has split rows).  The grid-wide reductions are closed in the
-// PROLOGUE of the next kernel: every workgroup sums the same partials in the same fixed order, so all
-// of them hold bit-identical alpha / beta without atomics, a separate reduce launch or a grid barrier,
-// and results are reproducible run to run.
+// (+ k_long_finish when the graph has split rows; on graphs whose x exceeds the caches k_spmv keeps only
+// the LDS-staged hub columns and lzx_pb.hip's two streaming passes add the rest into v).  The grid-wide
+// reductions are closed in the PROLOGUE of the next kernel: every workgroup sums the same partials in the
+// same fixed order, so all of them hold bit-identical alpha / beta without global atomics, a separate
+// reduce launch or a grid barrier, and results are reproducible run to run.
 #include "lzx_internal.h"
 
 // --------------------------------------------------------------------------------------------------
