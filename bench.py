@@ -170,7 +170,8 @@ def main():
                 "k": K, "x0": "ones",
                 "partition": "single GPU" if world == 1 else
                              f"rows dealt round-robin by degree rank over {world} GPUs; per iteration 1 RCCL "
-                             f"all-gather of {8 * gi['n'] // world} B per rank + 2 one-double all-reduces",
+                             f"all-gather of {8 * gi['exchange_slice']} B per rank (only the {gi['active_vertices']} "
+                             f"vertices that have an edge are exchanged) + 2 one-double all-reduces",
                 "graph_build_s": round(t_gen, 3),
                 "lanczos_coefficients_finite": finite,
             },

@@ -64,6 +64,8 @@ typedef struct lzx_graph_info {
     uint64_t long_rows;   /* local rows handled by the split-row path            */
     uint64_t sell_padded; /* entries of the sliced-ELL body including padding    */
     uint64_t pb_entries;  /* local entries handled by the propagation-blocked passes (0 = mode off) */
+    uint64_t active_vertices; /* vertices with at least one edge (global)         */
+    uint64_t exchange_slice;  /* doubles each rank contributes to the per-iteration all-gather */
     uint32_t hub_entries; /* x entries staged in LDS per workgroup               */
     uint32_t world, rank;
 } lzx_graph_info;

@@ -36,7 +36,8 @@ class LzxGraphInfo(ctypes.Structure):
     _fields_ = [("n", ctypes.c_uint64), ("nnz", ctypes.c_uint64), ("max_degree", ctypes.c_uint64),
                 ("rows_local", ctypes.c_uint64), ("nnz_local", ctypes.c_uint64),
                 ("long_rows", ctypes.c_uint64), ("sell_padded", ctypes.c_uint64),
-                ("pb_entries", ctypes.c_uint64), ("hub_entries", ctypes.c_uint32), ("world", ctypes.c_uint32), ("rank", ctypes.c_uint32)]
+                ("pb_entries", ctypes.c_uint64), ("active_vertices", ctypes.c_uint64),
+                ("exchange_slice", ctypes.c_uint64), ("hub_entries", ctypes.c_uint32), ("world", ctypes.c_uint32), ("rank", ctypes.c_uint32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

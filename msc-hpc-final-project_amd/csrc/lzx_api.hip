@@ -205,9 +205,12 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
         if (!multi) {
             LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_Q, x_norm));
         } else {
-            LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_xbuf, x_norm));
-            LZX_HIP(hipMemcpyAsync(c->d_Q, c->d_xbuf + (size_t)c->rank * c->n_loc_pad,
+            // every rank holds all of x0: full vector in hand-over layout, own slice into the basis, and the
+            // prefix of every slice that carries vertices with an edge into the exchange buffer (no communication)
+            LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_ybuf, x_norm));
+            LZX_HIP(hipMemcpyAsync(c->d_Q, c->d_ybuf + (size_t)c->rank * c->n_loc_pad,
                                    sizeof(double) * c->n_loc_pad, hipMemcpyDeviceToDevice, c->stream));
+            LZX_TRY(lzx_launch_relayout(c, c->d_ybuf, c->d_xbuf));
         }
     }
     LZX_TRY(sync_all(cs));
@@ -298,7 +301,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
                 src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
                 dst[i] = cs[i]->d_xbuf;
             }
-            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs));   // only the prefix that has edges
             LZX_HIP(hipSetDevice(c0->device));
             LZX_TRY(mk.tick(CAT_COMM));
         }
@@ -352,7 +355,7 @@ static int lanczos_fetch(std::vector<lzx_ctx *> &cs, u32 k, double *alpha, doubl
                     src[i] = cs[i]->d_Q + (size_t)j * cs[i]->ldq;
                     dst[i] = cs[i]->d_ybuf;
                 }
-                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->n_loc_pad));
             }
             LZX_HIP(hipSetDevice(c0->device));
             LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_Q + (size_t)j * c0->ldq, c0->d_io));
@@ -429,13 +432,15 @@ static int spmv_run(std::vector<lzx_ctx *> &cs, const double *x, double *y)
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
         LZX_HIP(hipMemcpyAsync(c->d_io, x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
-        LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_xbuf, 1.0));
-        SpmvLaunch l{c->d_xbuf, c->d_xbuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
+        // x in hand-over layout (d_ybuf); the SpMV gathers from the exchange layout (d_xbuf; the same thing at one rank)
+        LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_ybuf, 1.0));
+        if (multi) LZX_TRY(lzx_launch_relayout(c, c->d_ybuf, c->d_xbuf));
+        SpmvLaunch l{multi ? c->d_xbuf : c->d_ybuf, c->d_ybuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
         LZX_TRY(lzx_launch_spmv(c, l));
     }
     if (multi) {
         for (size_t i = 0; i < cs.size(); ++i) { src[i] = cs[i]->d_v; dst[i] = cs[i]->d_ybuf; }
-        LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+        LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->n_loc_pad));
     }
     LZX_HIP(hipSetDevice(c0->device));
     LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_v, c0->d_io));
@@ -477,7 +482,7 @@ static int multout_run(std::vector<lzx_ctx *> &cs, const double *t, u32 k, doubl
     }
     if (multi) {
         for (size_t i = 0; i < cs.size(); ++i) { src[i] = cs[i]->d_v; dst[i] = cs[i]->d_ybuf; }
-        LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data()));
+        LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->n_loc_pad));
     }
     LZX_HIP(hipSetDevice(c0->device));
     LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_v, c0->d_io));
@@ -508,8 +513,9 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
     // a non-trivial resident input: x = 1 everywhere
     std::vector<double> ones(c->n, 1.0);
     LZX_HIP(hipMemcpyAsync(c->d_io, ones.data(), sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
-    LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_xbuf, 1.0));
-    SpmvLaunch l{c->d_xbuf, c->d_xbuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
+    LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_ybuf, 1.0));
+    if (c->world > 1) LZX_TRY(lzx_launch_relayout(c, c->d_ybuf, c->d_xbuf));
+    SpmvLaunch l{c->world > 1 ? c->d_xbuf : c->d_ybuf, c->d_ybuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
     LZX_TRY(lzx_launch_spmv(c, l));  // warm-up
     LZX_HIP(hipStreamSynchronize(c->stream));
     double total = 0.0, best = 1e300;

@@ -177,11 +177,10 @@ int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot)
     return LZX_OK;
 }
 
-// dst_full[i][p * n_loc_pad ...] <- src_loc[p][0 .. n_loc_pad) for every rank p, on every handle i.
-int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full)
+// dst_full[i][p * cnt ...] <- src_loc[p][0 .. cnt) for every rank p, on every handle i.
+int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t cnt)
 {
     lzx_ctx *c0 = cs[0];
-    const size_t cnt = c0->n_loc_pad;
     if (c0->world == 1) {
         if (dst_full[0] != src_loc[0])
             LZX_HIP(hipMemcpyAsync(dst_full[0], src_loc[0], cnt * sizeof(double), hipMemcpyDeviceToDevice, c0->stream));

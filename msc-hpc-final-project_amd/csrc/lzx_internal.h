@@ -84,9 +84,14 @@ struct lzx_ctx {
     u32 n_loc_real = 0;                // rows owned
     u32 n_loc_pad = 0;                 // slice stride of the exchanged vector (multiple of 64, same on all ranks)
     u32 ldq = 0;                       // stride between basis vectors = n_loc_pad + LZX_TAIL
-    u64 xlen = 0;                      // world * n_loc_pad + LZX_TAIL
+    u32 xs = 0;                        // slice stride of the PER-ITERATION exchange: only vertices with an edge are
+                                       // exchanged (local rows are degree-sorted, so they are a prefix of every slice);
+                                       // = n_loc_pad at one rank, round_up(ceil(n_active / world), 64) otherwise
+    u64 n_active = 0;                  // vertices of degree > 0
+    u64 xlen = 0;                      // world * xs + LZX_TAIL: length of the vector the SpMV gathers from
+    u64 iolen = 0;                     // world * n_loc_pad + LZX_TAIL: full-length layout of hand-over / results
     u64 nnz_local = 0;
-    u32 *d_gidx_of_old = nullptr;      // [n] position of caller's vertex o in the full-length layout
+    u32 *d_gidx_of_old = nullptr;      // [n] position of caller's vertex o in the full-length (iolen) layout
     u32 hub = 0;                       // entries staged in LDS
     int64_t hub_opt = -1;              // user override (-1: default)
     int64_t wgs_per_cu_opt = -1;
@@ -140,8 +145,8 @@ struct lzx_ctx {
     u32 q_cols = 0;
     u32 k_last = 0;                    // valid basis vectors from the last decomposition
     u32 k_prep = 0;                    // iterations a prepared (not yet run) decomposition will take
-    double *d_xbuf = nullptr;          // [xlen] full-length exchange buffer
-    double *d_ybuf = nullptr;          // [xlen] second full-length buffer (hooks, multout)
+    double *d_xbuf = nullptr;          // [xlen] exchange buffer the SpMV gathers from (world > 1, hooks)
+    double *d_ybuf = nullptr;          // [iolen] full-length buffer in hand-over layout (hooks, multout, fetch)
     double *d_io = nullptr;            // [n] staging in the caller's order
     double *d_partials = nullptr;      // [np_cap] block partials of the running reduction
     double *d_partials2 = nullptr;     // [np_cap]
@@ -188,9 +193,11 @@ int lzx_launch_scale(lzx_ctx *c, const double *v, double *q_next, const double *
                      u32 np_in, double *beta_out);
 int lzx_launch_permute_in(lzx_ctx *c, const double *io_old_order, double *full, double scale);
 int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io_old_order);
+// hand-over layout (stride n_loc_pad) -> exchange layout (stride xs): the active prefix of every rank's slice
+int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_layout);
 int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc);
 
 // ---- lzx_comm.hip ----
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot);        // d_scal[slot] on every handle
-int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full);
+int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t count);
 void lzx_comm_release(lzx_ctx *c);

@@ -57,7 +57,7 @@ struct SpmvArgs {
     u32 hub;       // LDS slots (staged values + zero slots)
     u32 hub_real;  // slots that carry x values
     u32 world;
-    u32 n_loc_pad;
+    u32 xs;        // slice stride of the exchange layout
 };
 
 // Column code c: c < hub -> value staged in LDS slot c; otherwise x[c - hub].
@@ -96,9 +96,9 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
 
     if (HUB) {
         // Stage x of the `hub` highest-degree vertices once per workgroup (coalesced at world == 1;
-        // `world` strided segments otherwise: degree rank r lives at (r % world) * n_loc_pad + r / world).
+        // `world` strided segments otherwise: degree rank r lives at (r % world) * xs + r / world).
         for (u32 i = tid; i < a.hub; i += LZX_SPMV_BLOCK) {
-            const u32 g = (a.world == 1) ? i : (i % a.world) * a.n_loc_pad + i / a.world;
+            const u32 g = (a.world == 1) ? i : (i % a.world) * a.xs + i / a.world;
             hubv[i] = i < a.hub_real ? a.x[g] : 0.0;
         }
         __syncthreads();
@@ -380,6 +380,15 @@ __global__ void k_permute_in(const double *io, const u32 *gidx, double *full, do
     if (o < n) full[gidx[o]] = io[o] / div;
 }
 
+// hand-over layout [world][n_loc_pad] -> exchange layout [world][xs]: the first xs entries of every slice
+__global__ void k_relayout(const double *io_layout, double *x, u32 world, u32 n_loc_pad, u32 xs)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u64)world * xs) return;
+    const u32 p = (u32)(i / xs), l = (u32)(i % xs);
+    x[i] = io_layout[(size_t)p * n_loc_pad + l];
+}
+
 __global__ void k_permute_out(const double *full, const u32 *gidx, double *io, u64 n)
 {
     const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -439,7 +448,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.hub = c->hub;
     a.hub_real = c->hub_real;
     a.world = (u32)c->world;
-    a.n_loc_pad = c->n_loc_pad;
+    a.xs = c->xs;
     const bool nt = c->nt_opt > 0;
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[0], c->stream));
     if (c->hub > 0) {
@@ -505,6 +514,15 @@ int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io)
     if (c->n == 0) return LZX_OK;
     const u32 g = (u32)((c->n + 255) / 256);
     hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, c->stream, full, c->d_gidx_of_old, io, c->n);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_layout)
+{
+    const u64 cnt = (u64)c->world * c->xs;
+    hipLaunchKernelGGL(k_relayout, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, c->stream, io_layout, exchange_layout,
+                       (u32)c->world, c->n_loc_pad, c->xs);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }

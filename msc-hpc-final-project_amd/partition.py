@@ -5,8 +5,11 @@ rehearse the N > 1 exchange pattern on CPU.
 Rules (identical on every rank, no communication needed to agree on them):
   * vertices are ranked by degree, descending, ties by the caller's id (stable);
   * degree rank r is owned by rank r % world, at local row r // world;
-  * every rank's slice of an exchanged vector is n_loc_pad = round_up(ceil(n / world), 64) long, so the
-    all-gather moves equal-sized slices; degree rank r sits at position (r % world) * n_loc_pad + r // world.
+  * a rank's slice of a full-length vector is n_loc_pad = round_up(ceil(n / world), 64) long; degree rank r sits at
+    position (r % world) * n_loc_pad + r // world;
+  * the per-iteration exchange only moves vertices that have an edge: they are the first n_active degree ranks, hence
+    a prefix of every slice, xs = round_up(ceil(n_active / world), 64) long (R-MAT graphs are ~40 % isolated
+    vertices); in that exchange layout degree rank r sits at (r % world) * xs + r // world.
 Replaces the reference's split at rows0 = 0.5 * n (parallel-two-cards/lib/cu_lanczos.cu:62-64), which
 balances rows, not work.
 """
@@ -26,6 +29,21 @@ def degree_order(row_ptr: np.ndarray) -> np.ndarray:
 def slice_len(n: int, world: int) -> int:
     per = -(-n // world)
     return -(-per // SLICE) * SLICE
+
+
+def exchange_len(row_ptr: np.ndarray, world: int) -> int:
+    """xs: how many entries of each rank's slice the per-iteration all-gather moves."""
+    deg = np.diff(np.asarray(row_ptr).astype(np.int64))
+    n_active = int((deg > 0).sum())
+    per = -(-n_active // world)
+    return min(max(SLICE, -(-per // SLICE) * SLICE), slice_len(len(deg), world))
+
+
+def exchange_positions(row_ptr: np.ndarray, world: int) -> np.ndarray:
+    """pos[r] = position of degree rank r in the exchange layout (meaningful for r < n_active)."""
+    n = len(row_ptr) - 1
+    r = np.arange(n, dtype=np.int64)
+    return (r % world) * exchange_len(row_ptr, world) + r // world
 
 
 def positions(n: int, world: int) -> np.ndarray:

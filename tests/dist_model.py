@@ -13,10 +13,12 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
     world, rank = dist.get_world_size(), dist.get_rank()
     n = len(row_ptr) - 1
     order = P.degree_order(row_ptr)
-    pos = P.positions(n, world)                 # degree rank -> position in the exchange layout
-    L = P.slice_len(n, world)
-    pos_of_old = np.empty(n, dtype=np.int64)
-    pos_of_old[order] = pos
+    L = P.slice_len(n, world)                   # local vector length (all owned rows)
+    X = P.exchange_len(row_ptr, world)          # exchanged prefix: vertices with an edge only
+    deg = np.diff(row_ptr.astype(np.int64))
+    n_active = int((deg > 0).sum())
+    pos_of_old = np.full(n, -1, dtype=np.int64)  # exchange-layout position; isolated vertices are never gathered
+    pos_of_old[order[:n_active]] = P.exchange_positions(row_ptr, world)[:n_active]
     mine = P.local_vertices(order, world, rank)  # caller's ids of my rows, local order
     rp = row_ptr.astype(np.int64)
     # my rows' columns translated to exchange-layout positions, caller's column order kept
@@ -36,20 +38,24 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
         dist.all_reduce(t)
         return float(t.item())
 
-    def allgather(loc):
-        outs = [torch.empty(L, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(outs, torch.from_numpy(np.ascontiguousarray(loc)))
+    def allgather(loc, count):
+        outs = [torch.empty(count, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(outs, torch.from_numpy(np.ascontiguousarray(loc[:count])))
         return torch.cat(outs).numpy()
 
     xn = np.sqrt(np.sum(x0 * x0))
-    xfull = np.zeros(world * L)
-    xfull[pos_of_old] = x0 / xn
-    q = xfull[rank * L:(rank + 1) * L].copy()
+    q = np.zeros(L)
+    q[:len(mine)] = x0[mine] / xn               # every rank holds all of x0: no exchange to start
+    xfull = np.zeros(world * X)
+    act = pos_of_old >= 0
+    xfull[pos_of_old[act]] = x0[act] / xn
     q_prev = np.zeros(L)
     alpha, beta = np.zeros(k), np.zeros(max(k - 1, 1))
     Q = np.zeros((k, n))
+    io_pos = np.empty(n, dtype=np.int64)         # result layout: stride L
+    io_pos[order] = P.positions(n, world)
     for j in range(k):
-        Q[j] = xfull[pos_of_old]
+        Q[j] = allgather(q, L)[io_pos]           # result gather (not part of the iteration's exchange)
         v = spmv_local(xfull)
         alpha[j] = allreduce(float(v @ q))
         if j == k - 1:
@@ -59,5 +65,5 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
             v = v - beta[j - 1] * q_prev
         beta[j] = np.sqrt(allreduce(float(v @ v)))
         q_prev, q = q, v / beta[j]
-        xfull = allgather(q)
+        xfull = allgather(q, X)                  # the per-iteration exchange: the prefix with edges only
     return alpha, beta[:k - 1], Q, xn
