@@ -45,6 +45,11 @@ extern "C" int lzx_create(lzx_handle *out, int device_id)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_a);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_b);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_phase2, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_scal), sizeof(double) * (8 + 64));
     if (e != hipSuccess) {
         lzx_set_error("lzx_create: %s", hipGetErrorString(e));
@@ -70,6 +75,11 @@ extern "C" void lzx_destroy(lzx_handle c)
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->ev_phase) (void)hipEventDestroy(c->ev_phase);
+    if (c->ev_phase2) (void)hipEventDestroy(c->ev_phase2);
+    if (c->ev_q) (void)hipEventDestroy(c->ev_q);
+    if (c->ev_c0) (void)hipEventDestroy(c->ev_c0);
+    if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -83,6 +93,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "nt_index_loads")) c->nt_opt = value;
     else if (!strcmp(name, "long_row")) c->long_row_opt = value;
     else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
+    else if (!strcmp(name, "overlap_exchange")) c->overlap_opt = value;
     else if (!strcmp(name, "pb_target")) c->pb_target_opt = value;
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
@@ -127,6 +138,7 @@ static int sync_all(std::vector<lzx_ctx *> &cs)
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
         LZX_HIP(hipStreamSynchronize(c->stream));
+        LZX_HIP(hipStreamSynchronize(c->stream2));
     }
     return LZX_OK;
 }
@@ -239,12 +251,23 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     std::vector<double *> dst(cs.size());
     const u32 np = lzx_spmv_partials(c0);
 
+    const bool overlap = multi && c0->overlap;
     for (u32 j = 0; j < k; ++j) {
         // v = A q_j ; partials of alpha_j
+        if (overlap && j > 0) {
+            // chunk 0 of q_j (the high-degree end of every slice, where the staged hub entries and nearly all
+            // gathers are) has to be here; chunk 1 may still be on the wire while the SpMV works on chunk 0
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_HIP(hipStreamWaitEvent(c->stream, c->ev_c0, 0));
+            }
+            LZX_TRY(mk.tick(CAT_COMM));
+        }
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
             const double *qj = c->d_Q + (size_t)j * c->ldq;
             SpmvLaunch l{multi ? c->d_xbuf : qj, qj, c->d_v, c->d_partials};
+            if (overlap && j > 0) l.chunk1_ready = c->ev_c1;
             LZX_TRY(lzx_launch_spmv(c, l));
         }
         LZX_TRY(mk.tick(CAT_SPMV));
@@ -296,7 +319,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         }
         LZX_TRY(mk.tick(CAT_VEC));
 
-        if (multi) {
+        if (multi && !overlap) {
             for (size_t i = 0; i < cs.size(); ++i) {
                 src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
                 dst[i] = cs[i]->d_xbuf;
@@ -304,6 +327,29 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs));   // only the prefix that has edges
             LZX_HIP(hipSetDevice(c0->device));
             LZX_TRY(mk.tick(CAT_COMM));
+        }
+        if (overlap) {
+            // exchange streams: both chunks of q_{j+1} back to back, an event after each.  They start once every
+            // handle's k_scale is done (which also means every SpMV that read the previous x is done).
+            LZX_TRY(lzx_comm_order(cs, /*from main*/ false, /*to exchange*/ true));
+            for (size_t i = 0; i < cs.size(); ++i) {
+                src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
+                dst[i] = cs[i]->d_xbuf;
+            }
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs0, true));
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_HIP(hipEventRecord(c->ev_c0, c->stream2));
+            }
+            for (size_t i = 0; i < cs.size(); ++i) {
+                src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq + cs[i]->xs0;
+                dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
+            }
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_HIP(hipEventRecord(c->ev_c1, c->stream2));
+            }
         }
     }
     LZX_TRY(sync_all(cs));

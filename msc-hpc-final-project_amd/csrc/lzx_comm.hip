@@ -138,20 +138,27 @@ void lzx_comm_release(lzx_ctx *c)
     c->rank = 0;
 }
 
-// Make every stream in cs wait for everything queued so far on every other stream in cs.
-static int cross_barrier(std::vector<lzx_ctx *> &cs)
+static hipStream_t pick(lzx_ctx *c, bool s2) { return s2 ? c->stream2 : c->stream; }
+
+// Everything queued so far on every handle's `from` stream happens before what is queued next on every handle's
+// `to` stream (all pairs, own handle included when the two streams differ).
+int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream2)
 {
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
-        LZX_HIP(hipEventRecord(c->ev_phase, c->stream));
+        LZX_HIP(hipEventRecord(from_stream2 ? c->ev_phase2 : c->ev_phase, pick(c, from_stream2)));
     }
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
         for (lzx_ctx *p : cs)
-            if (p != c) LZX_HIP(hipStreamWaitEvent(c->stream, p->ev_phase, 0));
+            if (p != c || from_stream2 != to_stream2)
+                LZX_HIP(hipStreamWaitEvent(pick(c, to_stream2), from_stream2 ? p->ev_phase2 : p->ev_phase, 0));
     }
     return LZX_OK;
 }
+
+// Make every stream in cs wait for everything queued so far on every other stream in cs.
+static int cross_barrier(std::vector<lzx_ctx *> &cs, bool s2 = false) { return lzx_comm_order(cs, s2, s2); }
 
 // d_scal[slot] <- sum over ranks of d_scal[slot], on every handle.
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot)
@@ -177,31 +184,34 @@ int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot)
     return LZX_OK;
 }
 
-// dst_full[i][p * cnt ...] <- src_loc[p][0 .. cnt) for every rank p, on every handle i.
-int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t cnt)
+// dst_full[i][p * cnt ...] <- src_loc[p][0 .. cnt) for every rank p, on every handle i; on the handles' main streams
+// or (on_stream2) on their exchange streams.
+int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t cnt,
+                       bool on_stream2)
 {
     lzx_ctx *c0 = cs[0];
+    if (cnt == 0) return LZX_OK;
     if (c0->world == 1) {
         if (dst_full[0] != src_loc[0])
-            LZX_HIP(hipMemcpyAsync(dst_full[0], src_loc[0], cnt * sizeof(double), hipMemcpyDeviceToDevice, c0->stream));
+            LZX_HIP(hipMemcpyAsync(dst_full[0], src_loc[0], cnt * sizeof(double), hipMemcpyDeviceToDevice, pick(c0, on_stream2)));
         return LZX_OK;
     }
     if (c0->comm_kind == 2) {
         LZX_NCCL(g_rccl.AllGather(src_loc[0], dst_full[0], cnt, ncclDouble,
-                                  static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
+                                  static_cast<ncclComm_t>(c0->nccl_comm), pick(c0, on_stream2)));
         return LZX_OK;
     }
     const int world = c0->world;
     if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
-    LZX_TRY(cross_barrier(cs));
+    LZX_TRY(cross_barrier(cs, on_stream2));
     for (int i = 0; i < world; ++i) {
         LZX_HIP(hipSetDevice(cs[i]->device));
         for (int p = 0; p < world; ++p) {
             double *dst = dst_full[i] + (size_t)p * cnt;
             if (dst == src_loc[p]) continue;
-            LZX_HIP(hipMemcpyAsync(dst, src_loc[p], cnt * sizeof(double), hipMemcpyDefault, cs[i]->stream));
+            LZX_HIP(hipMemcpyAsync(dst, src_loc[p], cnt * sizeof(double), hipMemcpyDefault, pick(cs[i], on_stream2)));
         }
     }
-    LZX_TRY(cross_barrier(cs));
+    LZX_TRY(cross_barrier(cs, on_stream2));
     return LZX_OK;
 }

@@ -76,13 +76,15 @@ __global__ void k_degrees(const u64 *row_ptr, u32 *deg, u32 *ids, u64 n)
 
 // degree rank r -> position in the exchange layout and column code
 __global__ void k_rank_maps(const u32 *sorted_ids, u32 *gidx_of_old, u32 *code_of_old, u64 n,
-                            u32 world, u32 n_loc_pad, u32 xs, u32 hub)
+                            u32 world, u32 n_loc_pad, u32 xs, u32 xs0, u32 hub)
 {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const u32 o = sorted_ids[r];
-    gidx_of_old[o] = (u32)(r % world) * n_loc_pad + (u32)(r / world);   // hand-over / result layout
-    const u32 x = (u32)(r % world) * xs + (u32)(r / world);             // exchange layout (meaningful for degree > 0)
+    const u32 p = (u32)(r % world), l = (u32)(r / world);
+    gidx_of_old[o] = p * n_loc_pad + l;   // hand-over / result layout
+    // exchange layout (meaningful for degree > 0): chunk 0 = [world][xs0], chunk 1 = [world][xs - xs0]
+    const u32 x = l < xs0 ? p * xs0 + l : world * xs0 + p * (xs - xs0) + (l - xs0);
     code_of_old[o] = (r < hub) ? (u32)r : hub + x;
 }
 
@@ -246,6 +248,10 @@ int lzx_graph_prepare(lzx_ctx *c)
     // bands than wavefronts) eat the gain when a rank's share is small (tools/rank_probe.py, C3 per-rank SpMV, plain /
     // blocked: P=2 1.10 / 0.95, P=4 0.59 / 0.55, P=8 0.305 / 0.327 ms).  -1 = decide here.
     bool pb = c->pb_opt > 0 || (c->pb_opt < 0 && n >= (4u << 20) && c->nnz / (u64)world >= (64u << 20));
+    // ... but only the blocked SpMV can start on the first chunk of the exchange while the second is still on the
+    // wire (its scatter walks column bands in order), which is worth more than those fixed costs: with several ranks
+    // and the overlapped exchange allowed, block from 16 Mi entries per rank.
+    if (c->pb_opt < 0 && world > 1 && c->overlap_opt != 0 && n >= (4u << 20) && c->nnz / (u64)world >= (16u << 20)) pb = true;
     // hub entries staged in LDS by k_spmv: 8192 (64 KiB, two workgroups per CU) when k_spmv also gathers from
     // memory; 16384 (128 KiB, one per CU) in propagation-blocking mode, where it only ever reads LDS.
     u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : (pb ? 16384 : 8192);
@@ -315,6 +321,17 @@ int lzx_graph_prepare(lzx_ctx *c)
         c->xs = std::min(c->xs, c->n_loc_pad);
         c->xlen = (u64)world * c->xs + LZX_TAIL;
     }
+    // Two chunks (see lzx_internal.h: xs0) when the blocked SpMV will run on several ranks: chunk 0 is the first eighth
+    // of every slice, rounded so that chunk 0 ends on a column-band boundary, and must hold the LDS-staged hub entries.
+    c->xs0 = c->xs;
+    c->overlap = false;
+    if (world > 1 && pb && c->overlap_opt != 0) {
+        u32 x0 = round_up(std::max<u32>(c->xs / 8, (c->hub_real + world - 1) / world), LZX_PB_CB);
+        if (x0 < c->xs) {
+            c->xs0 = x0;
+            c->overlap = true;
+        }
+    }
     if (c->hub_real > c->n_active) {
         // staged slots beyond the vertices that have edges would never be referenced (and, with several ranks, would
         // lie outside the exchanged prefix)
@@ -324,9 +341,13 @@ int lzx_graph_prepare(lzx_ctx *c)
         c->spmv_lds = ((size_t)c->hub + LZX_SPMV_BLOCK / 64) * sizeof(double);
     }
     if (c->hub_real >= c->n_active) pb = false;   // every referenced column is staged: nothing left to block
+    if (!pb) {
+        c->xs0 = c->xs;
+        c->overlap = false;
+    }
     const u32 sentinel = pb ? c->hub_real : c->hub + (u32)((u64)world * c->xs);
     hipLaunchKernelGGL(k_rank_maps, dim3(gb), dim3(256), 0, st, d_sids, c->d_gidx_of_old, d_code, n,
-                       world, c->n_loc_pad, c->xs, c->hub_real);
+                       world, c->n_loc_pad, c->xs, c->xs0, c->hub_real);
 
     // ---- 2. this rank's rows ----
     PREP(dev_alloc(&d_old_of_local, c->n_loc_real)); PREP(dev_alloc(&d_deg_local, c->n_loc_real));

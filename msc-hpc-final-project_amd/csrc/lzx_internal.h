@@ -63,6 +63,9 @@ struct lzx_ctx {
     int device = 0;
     int cu_count = 256;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;                    // exchange stream (chunked all-gather overlapping the SpMV)
+    hipEvent_t ev_q = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;   // q_{j+1} slice ready / chunk 0 / chunk 1 arrived
+    hipEvent_t ev_phase2 = nullptr;                   // cross-handle ordering on stream2 (local communicator)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;       // scratch timing pair
     hipEvent_t ev_phase = nullptr;                    // cross-handle ordering in local-comm mode
     std::vector<hipEvent_t> ev_pool;                  // per-iteration timing events
@@ -87,6 +90,10 @@ struct lzx_ctx {
     u32 xs = 0;                        // slice stride of the PER-ITERATION exchange: only vertices with an edge are
                                        // exchanged (local rows are degree-sorted, so they are a prefix of every slice);
                                        // = n_loc_pad at one rank, round_up(ceil(n_active / world), 64) otherwise
+    u32 xs0 = 0;                       // the exchange is cut in two chunks: the first xs0 entries of every slice (the
+                                       // high-degree end: nearly all gathers land there) and the remaining xs - xs0;
+                                       // layout [world][xs0] then [world][xs - xs0] so each chunk is one all-gather and
+                                       // the second one can travel while the SpMV already works on the first
     u64 n_active = 0;                  // vertices of degree > 0
     u64 xlen = 0;                      // world * xs + LZX_TAIL: length of the vector the SpMV gathers from
     u64 iolen = 0;                     // world * n_loc_pad + LZX_TAIL: full-length layout of hand-over / results
@@ -97,6 +104,9 @@ struct lzx_ctx {
     int64_t wgs_per_cu_opt = -1;
     int64_t nt_opt = -1;
     int64_t pb_opt = -1;               // propagation blocking: -1 auto, 0 off, 1 on
+    int64_t overlap_opt = -1;          // chunked exchange overlapping the blocked SpMV: -1 auto, 0 off, 1 on
+    bool overlap = false;
+    u32 pb_units0 = 0;                 // scatter units whose column band lies wholly in chunk 0
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
     int64_t long_row_opt = -1;         // split-row threshold override
@@ -171,7 +181,8 @@ int lzx_graph_prepare(lzx_ctx *c);   // builds this rank's share from d_row_ptr/
 int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, const u32 *d_deg_local,
                    const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total);
 void lzx_pb_release(lzx_ctx *c);
-int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials);
+// chunk1_ready (may be null): event after which the second chunk of the exchange layout is valid in x
+int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready);
 u32 lzx_pb_partials(const lzx_ctx *c);
 
 // ---- lzx_kernels.hip ----
@@ -180,6 +191,7 @@ struct SpmvLaunch {
     const double *q_loc;   // this rank's slice of it (for the fused alpha partial)
     double *v;             // [n_loc_pad] output
     double *partials;      // block partials of v.q_loc ; count returned by lzx_spmv_partials()
+    hipEvent_t chunk1_ready = nullptr;   // overlapped exchange: columns of chunk 1 may be read only after this event
 };
 int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &a);
 u32 lzx_spmv_partials(const lzx_ctx *c);
@@ -199,5 +211,8 @@ int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc);
 
 // ---- lzx_comm.hip ----
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot);        // d_scal[slot] on every handle
-int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t count);
+int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t count,
+                       bool on_stream2 = false);
+// everything queued so far on every handle's `from` stream happens before what is queued next on every `to` stream
+int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream2);
 void lzx_comm_release(lzx_ctx *c);

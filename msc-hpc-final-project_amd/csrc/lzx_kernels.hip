@@ -57,7 +57,7 @@ struct SpmvArgs {
     u32 hub;       // LDS slots (staged values + zero slots)
     u32 hub_real;  // slots that carry x values
     u32 world;
-    u32 xs;        // slice stride of the exchange layout
+    u32 xs0;       // slice stride of chunk 0 of the exchange layout (the staged hub entries all live there)
 };
 
 // Column code c: c < hub -> value staged in LDS slot c; otherwise x[c - hub].
@@ -96,9 +96,9 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
 
     if (HUB) {
         // Stage x of the `hub` highest-degree vertices once per workgroup (coalesced at world == 1;
-        // `world` strided segments otherwise: degree rank r lives at (r % world) * xs + r / world).
+        // `world` strided segments otherwise: degree rank r lives at (r % world) * xs0 + r / world, in chunk 0).
         for (u32 i = tid; i < a.hub; i += LZX_SPMV_BLOCK) {
-            const u32 g = (a.world == 1) ? i : (i % a.world) * a.xs + i / a.world;
+            const u32 g = (a.world == 1) ? i : (i % a.world) * a.xs0 + i / a.world;
             hubv[i] = i < a.hub_real ? a.x[g] : 0.0;
         }
         __syncthreads();
@@ -381,11 +381,19 @@ __global__ void k_permute_in(const double *io, const u32 *gidx, double *full, do
 }
 
 // hand-over layout [world][n_loc_pad] -> exchange layout [world][xs]: the first xs entries of every slice
-__global__ void k_relayout(const double *io_layout, double *x, u32 world, u32 n_loc_pad, u32 xs)
+__global__ void k_relayout(const double *io_layout, double *x, u32 world, u32 n_loc_pad, u32 xs, u32 xs0)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (u64)world * xs) return;
-    const u32 p = (u32)(i / xs), l = (u32)(i % xs);
+    u32 p, l;
+    if (i < (u64)world * xs0) {
+        p = (u32)(i / xs0);
+        l = (u32)(i % xs0);
+    } else {
+        const u64 j = i - (u64)world * xs0;
+        p = (u32)(j / (xs - xs0));
+        l = xs0 + (u32)(j % (xs - xs0));
+    }
     x[i] = io_layout[(size_t)p * n_loc_pad + l];
 }
 
@@ -448,7 +456,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.hub = c->hub;
     a.hub_real = c->hub_real;
     a.world = (u32)c->world;
-    a.xs = c->xs;
+    a.xs0 = c->xs0;
     const bool nt = c->nt_opt > 0;
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[0], c->stream));
     if (c->hub > 0) {
@@ -467,7 +475,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     LZX_HIP(hipGetLastError());
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[2], c->stream));
     // entries whose column is not staged in LDS: two streaming passes that add into v (lzx_pb.hip)
-    LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, l.partials + c->spmv_grid + c->fin_grid));
+    LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, l.partials + c->spmv_grid + c->fin_grid, l.chunk1_ready));
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[4], c->stream));
     return LZX_OK;
 }
@@ -522,7 +530,7 @@ int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_la
 {
     const u64 cnt = (u64)c->world * c->xs;
     hipLaunchKernelGGL(k_relayout, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, c->stream, io_layout, exchange_layout,
-                       (u32)c->world, c->n_loc_pad, c->xs);
+                       (u32)c->world, c->n_loc_pad, c->xs, c->xs0);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }

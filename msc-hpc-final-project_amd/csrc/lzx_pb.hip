@@ -587,6 +587,14 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
             units.push_back(std::min(bstart[b + 1], s + unit_quads));
         }
     c->pb_units = (u32)(units.size() / 3);
+    // units are sorted by column band: those whose band ends inside chunk 0 of the exchange layout come first
+    c->pb_units0 = c->pb_units;
+    if (c->overlap) {
+        const u64 chunk0_end = (u64)c->world * c->xs0;
+        u32 u0 = 0;
+        while (u0 < c->pb_units && ((u64)units[3 * u0] + 1) * LZX_PB_CB <= chunk0_end) ++u0;
+        c->pb_units0 = u0;
+    }
     PB(pb_alloc(&c->d_pb_unit, units.size()));
     if (!units.empty())
         PB_HIP(hipMemcpyAsync(c->d_pb_unit, units.data(), sizeof(u32) * units.size(), hipMemcpyHostToDevice, st));
@@ -638,15 +646,24 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
     return LZX_OK;
 }
 
-int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials)
+int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready)
 {
     if (!c->pb) return LZX_OK;
     if (c->pb_units) {
         const size_t lds1 = ((size_t)LZX_PB_CB + 2) * sizeof(double);
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_scatter),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        hipLaunchKernelGGL(k_pb_scatter, dim3(c->pb_units), dim3(1024), lds1, c->stream, c->d_pb_unit,
-                           reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val);
+        // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
+        const u32 first = chunk1_ready ? c->pb_units0 : c->pb_units;
+        if (first)
+            hipLaunchKernelGGL(k_pb_scatter, dim3(first), dim3(1024), lds1, c->stream, c->d_pb_unit,
+                               reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val);
+        if (chunk1_ready) {
+            LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
+            if (c->pb_units > first)
+                hipLaunchKernelGGL(k_pb_scatter, dim3(c->pb_units - first), dim3(1024), lds1, c->stream, c->d_pb_unit + 3 * (size_t)first,
+                                   reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val);
+        }
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);

@@ -46,6 +46,25 @@ def exchange_positions(row_ptr: np.ndarray, world: int) -> np.ndarray:
     return (r % world) * exchange_len(row_ptr, world) + r // world
 
 
+PB_CB = 16384
+
+
+def chunk0_len(row_ptr: np.ndarray, world: int, hub: int = 16384) -> int:
+    """xs0: the exchange is cut into the first xs0 entries of every slice (high-degree end) and the rest, laid out
+    [world][xs0] then [world][xs - xs0], so that the blocked SpMV can start on chunk 0 while chunk 1 travels.
+    xs0 = xs (one chunk) when the slices are too short for that."""
+    xs = exchange_len(row_ptr, world)
+    x0 = -(-max(xs // 8, -(-hub // world)) // PB_CB) * PB_CB
+    return x0 if x0 < xs else xs
+
+
+def chunked_positions(n: int, world: int, xs: int, xs0: int) -> np.ndarray:
+    """pos[r] = position of degree rank r in the two-chunk exchange layout."""
+    r = np.arange(n, dtype=np.int64)
+    p, l = r % world, r // world
+    return np.where(l < xs0, p * xs0 + l, world * xs0 + p * (xs - xs0) + (l - xs0))
+
+
 def positions(n: int, world: int) -> np.ndarray:
     """pos[r] = position of degree rank r in the full-length exchange layout."""
     r = np.arange(n, dtype=np.int64)

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 
 
-def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
+def run_rank(pkg_partition, row_ptr, col_idx, x0, k, xs0=None):
     """Returns (alpha, beta, gathered full-length q vectors (k, n) in the caller's order) on every rank."""
     P = pkg_partition
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -17,8 +17,9 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
     X = P.exchange_len(row_ptr, world)          # exchanged prefix: vertices with an edge only
     deg = np.diff(row_ptr.astype(np.int64))
     n_active = int((deg > 0).sum())
+    X0 = X if xs0 is None else xs0              # two-chunk exchange layout: [world][X0] then [world][X - X0]
     pos_of_old = np.full(n, -1, dtype=np.int64)  # exchange-layout position; isolated vertices are never gathered
-    pos_of_old[order[:n_active]] = P.exchange_positions(row_ptr, world)[:n_active]
+    pos_of_old[order[:n_active]] = P.chunked_positions(n, world, X, X0)[:n_active]
     mine = P.local_vertices(order, world, rank)  # caller's ids of my rows, local order
     rp = row_ptr.astype(np.int64)
     # my rows' columns translated to exchange-layout positions, caller's column order kept
@@ -38,10 +39,17 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
         dist.all_reduce(t)
         return float(t.item())
 
-    def allgather(loc, count):
+    def allgather(loc, count, first=0):
         outs = [torch.empty(count, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(outs, torch.from_numpy(np.ascontiguousarray(loc[:count])))
+        dist.all_gather(outs, torch.from_numpy(np.ascontiguousarray(loc[first:first + count])))
         return torch.cat(outs).numpy()
+
+    def exchange(loc):
+        """chunk 0 of every slice, then chunk 1: two all-gathers into one buffer (in the product the SpMV starts on
+        chunk 0 while chunk 1 is still travelling)"""
+        if X0 == X:
+            return allgather(loc, X)
+        return np.concatenate([allgather(loc, X0), allgather(loc, X - X0, X0)])
 
     xn = np.sqrt(np.sum(x0 * x0))
     q = np.zeros(L)
@@ -65,5 +73,5 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k):
             v = v - beta[j - 1] * q_prev
         beta[j] = np.sqrt(allreduce(float(v @ v)))
         q_prev, q = q, v / beta[j]
-        xfull = allgather(q, X)                  # the per-iteration exchange: the prefix with edges only
+        xfull = exchange(q)                      # the per-iteration exchange: the prefix with edges only
     return alpha, beta[:k - 1], Q, xn

@@ -44,6 +44,9 @@ def _worker(rank, world, port, out_dir):
     dist.broadcast(uid, 0)
     assert uid[127].item() == 127
     alpha, beta, Q, xn = dist_model.run_rank(P, rp, ci, np.ones(n), k)
+    # the same with the exchange cut in two chunks (as the product does on large graphs): identical numbers
+    a2, b2, Q2, _ = dist_model.run_rank(P, rp, ci, np.ones(n), k, xs0=128)
+    assert np.array_equal(alpha, a2) and np.array_equal(beta, b2) and np.array_equal(Q, Q2)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == world
@@ -87,6 +90,8 @@ def test_partition_rules(pkg):
     pos = P.positions(6, 4)
     assert pos.tolist() == [0, 64, 128, 192, 1, 65]
     assert P.local_vertices(order, 4, 1).tolist() == [2, 4]
+    assert P.chunked_positions(10, 2, 64, 2).tolist() == [0, 2, 1, 3, 4, 66, 5, 67, 6, 68]
+    assert P.chunked_positions(6, 2, 64, 64).tolist() == [0, 64, 1, 65, 2, 66]
     assert P.nnz_per_rank(rp, 2).tolist() == [9 + 3 + 0, 7 + 1 + 0]
     # dealing by degree rank balances work: within 1 % on a skewed graph
     import __graft_entry__ as ge2

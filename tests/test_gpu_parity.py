@@ -166,6 +166,37 @@ def test_local_group_matches_single(oracle, pkg):
         grp.close()
 
 
+def test_local_group_overlapped_exchange(oracle, pkg):
+    """Large enough for the two-chunk exchange (chunk 0 = 32 Ki entries per rank here) to be in effect: the blocked
+    SpMV starts on chunk 0 while chunk 1 is copied on the exchange streams.  Same answers as one handle, and as with
+    the overlap switched off."""
+    O = oracle
+    rp, ci = O.gen_er(600000, 3000000, 77)
+    n, k = len(rp) - 1, 10
+    x0 = np.ones(n)
+    a_ref, b_ref, Q_ref, xn_ref, ans_ref = pipeline_ref(O, rp, ci, k, x0)
+    x = np.random.default_rng(9).random(n)
+    y_ref = O.spmv(rp, ci, x)
+    results = []
+    for overlap in (1, 0):
+        grp = pkg.LocalGroup([0, 0, 0], propagation_blocking=1, hub_entries=1024, overlap_exchange=overlap)
+        grp.set_graph_csr(rp, ci)
+        gi = grp.engines[1].info()
+        assert gi["pb_entries"] > 0 and 0 < gi["exchange_slice"] <= -(-gi["active_vertices"] // 3 // 64) * 64 + 64
+        assert np.allclose(grp.spmv(x), y_ref, rtol=1e-13, atol=0)
+        a, b, Q, xn, st = grp.lanczos(x0, k)
+        check_leading_coefficients(a, b, a_ref, b_ref, ("overlap", overlap))
+        check_recurrence(O, rp, ci, a, b, Q, ("overlap", overlap))
+        lam, V = O.eigen(a, b)
+        assert rel_inf(grp.multout(V @ (np.exp(lam) * (xn * V[0, :]))), ans_ref) <= REL_INF_TOL
+        results.append((a, b))
+        grp.close()
+    # the chunked layout changes which column band an entry belongs to, hence the order of its additions: same first
+    # coefficients to rounding, not bit for bit
+    assert abs(results[0][0][0] - results[1][0][0]) <= 1e-13 * abs(results[1][0][0])
+    assert abs(results[0][1][0] - results[1][1][0]) <= 1e-13 * abs(results[1][1][0])
+
+
 def test_rccl_world1(oracle, pkg):
     """RCCL transport at world = 1: communicator creation, symbol resolution, stream plumbing."""
     O = oracle
