@@ -116,14 +116,13 @@ def main():
     # blocked SpMV.  Which is faster depends on the node's xGMI and on the rank count, so both
     # are timed for a few untimed iterations and every rank adopts the faster one (max over ranks decides).
     tune = {}
-    eng, t_gen = make_engine()
-    if world > 1:
-        alt, _ = make_engine(overlap_exchange=0)
-        x_tune = np.ones(n)
-        for name, e in (("overlapped", eng), ("single", alt)):
+    if world == 1:
+        eng, t_gen = make_engine()
+    else:
+        def timed(e):
             best = float("inf")
             for _ in range(2):
-                e.lanczos_prepare(x_tune, 6)
+                e.lanczos_prepare(np.ones(n), 6)
                 e.sync()
                 dist.barrier()
                 t = time.perf_counter()
@@ -131,11 +130,26 @@ def main():
                 dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
                 best = min(best, float(dt.item()))
-            tune[name] = best / 6 * 1e3
-        if tune["single"] < tune["overlapped"]:
-            eng.close()
-            eng = alt
-        else:
+            return best / 6 * 1e3
+
+        eng, t_gen = make_engine(overlap_exchange=0)
+        tune["single"] = timed(eng)
+        alt, failed = None, 0.0
+        try:
+            alt, _ = make_engine()
+            if not alt.info()["pb_entries"]:
+                failed = 1.0       # this rank count / graph does not qualify for the overlapped mode: nothing to compare
+        except Exception as exc:   # an error (not a hang) on any rank sends everybody back to the single all-gather
+            print(f"[bench rank {rank}] overlapped exchange unavailable: {exc}", file=sys.stderr, flush=True)
+            failed = 1.0
+        flag = torch.tensor([failed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() == 0.0:
+            tune["overlapped"] = timed(alt)
+            if tune["overlapped"] < tune["single"]:
+                eng.close()
+                eng, alt = alt, None
+        if alt is not None:
             alt.close()
     gi = eng.info()
 
