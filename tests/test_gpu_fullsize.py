@@ -95,6 +95,31 @@ def test_edge_cases(pkg, oracle):
     a_ref, b_ref, _, _ = O.lanczos(rp, ci, 4, np.ones(n))
     assert abs(a[0] - a_ref[0]) <= 1e-11 * abs(a_ref[0]) and abs(b[0] - b_ref[0]) <= 1e-10 * b_ref[0]
     eng.close()
+    # the same star through the blocked path with a tiny hub: the centre is a single-row band cut into several
+    # gather items (70 000 entries > 2 x 32 Ki), the leaves form light bands of 1024 rows
+    eng = pkg.Engine(0, propagation_blocking=1, hub_entries=64)
+    eng.set_graph_edges(n, src, dst)
+    assert eng.info()["pb_entries"] > 0
+    y = eng.spmv(x)
+    assert np.isclose(y[0], x[1:].sum(), rtol=1e-13) and np.array_equal(y[1:], np.full(n - 1, x[0]))
+    a, b, Q, xn, _ = eng.lanczos(np.ones(n), 4)
+    assert abs(a[0] - float(al)) <= 1e-14 * float(al)
+    assert abs(b[0] - float(be2) ** 0.5) <= 1e-13 * float(be2) ** 0.5
+    eng.close()
+    # a "double star" (two centres sharing all leaves) + a clique of the first 300 vertices: rows that are heavy both
+    # in staged and in blocked columns, many equal rows inside one 64-entry step (replica slots)
+    m = 40000
+    leaves = np.arange(2, m, dtype=np.uint32)
+    cl = np.array([(i, j) for i in range(300) for j in range(i + 1, 300)], dtype=np.uint32)
+    src2 = np.concatenate([np.zeros(m - 2, dtype=np.uint32), np.ones(m - 2, dtype=np.uint32), cl[:, 0]])
+    dst2 = np.concatenate([leaves, leaves, cl[:, 1]])
+    for mode in (dict(propagation_blocking=1, hub_entries=16), dict(propagation_blocking=1, hub_entries=128), dict(propagation_blocking=0)):
+        eng = pkg.Engine(0, **mode)
+        eng.set_graph_edges(m, src2, dst2)
+        rp2, ci2 = eng.get_graph_csr()
+        xr = np.random.default_rng(5).random(m)
+        assert np.allclose(eng.spmv(xr), O.spmv(rp2, ci2, xr), rtol=1e-13, atol=0), mode
+        eng.close()
     # arguments
     eng = pkg.Engine(0)
     with pytest.raises(pkg.LzxError):
