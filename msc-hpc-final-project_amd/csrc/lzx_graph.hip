@@ -377,20 +377,20 @@ int lzx_graph_prepare(lzx_ctx *c)
         u64 hub_total = 0;
         for (u32 l = 0; l < c->n_loc_real; ++l) hub_total += degl[l];
         pb_total = c->nnz_local - hub_total;
-        if (pb_total == 0 || pb_total >= (1ull << 32) - 8) pb = false;
-        if (pb) {
+        if (pb_total >= (1ull << 31)) {
+            lzx_set_error("propagation blocking: %llu entries on this rank exceed the 32-bit slot range", (unsigned long long)pb_total);
+            cleanup();
+            return LZX_ERR_LIMIT;
+        }
+        // pb_total == 0: every entry of this rank's rows has a staged column -- the hub-only structures are the whole
+        // matrix and no blocked tables are built (the layout decisions above stay as they are: other ranks block).
+        if (pb_total > 0) {
             size_t sb = 0;
             PREP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, d_nh_deg, d_nh_off, (u64)c->n_loc_real + 1, st));
             if (d_tmp) { (void)hipFree(d_tmp); d_tmp = nullptr; }
             PREP_HIP(hipMalloc(&d_tmp, sb ? sb : 16));
             PREP_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, sb, d_nh_deg, d_nh_off, (u64)c->n_loc_real + 1, st));
-        } else {
-            lzx_set_error("internal: propagation blocking chosen but not applicable");
-            cleanup();
-            return LZX_ERR_STATE;
         }
-    } else {
-        pb = false;
     }
 
     // ---- 3. host: split rows / slices (local rows are sorted by degree, descending) ----
@@ -469,7 +469,7 @@ int lzx_graph_prepare(lzx_ctx *c)
                                d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, c->d_long_cols, sentinel);
     }
     PREP_HIP(hipGetLastError());
-    if (pb) {
+    if (pb && pb_total > 0) {
         if (d_tmp) { (void)hipFree(d_tmp); d_tmp = nullptr; }
         PREP(lzx_pb_prepare(c, d_code, d_old_of_local, d_deg_local, d_nh_off, h_nh, pb_total));
     }

@@ -106,6 +106,18 @@ def test_edge_cases(pkg, oracle):
     assert abs(a[0] - float(al)) <= 1e-14 * float(al)
     assert abs(b[0] - float(be2) ** 0.5) <= 1e-13 * float(be2) ** 0.5
     eng.close()
+    # ... and over three in-process ranks: ranks 1 and 2 own only leaves, whose single entry is the staged centre, so
+    # they build no blocked tables at all while rank 0 (the centre's row) does
+    grp = pkg.LocalGroup([0, 0, 0], propagation_blocking=1, hub_entries=64)
+    rp_s, ci_s = O.csr_from_keys(n, np.concatenate([(np.uint64(0) << np.uint64(32)) | dst.astype(np.uint64),
+                                                    (dst.astype(np.uint64) << np.uint64(32))]))
+    grp.set_graph_csr(rp_s, ci_s)
+    assert [e.info()["pb_entries"] > 0 for e in grp.engines] == [True, False, False]
+    y = grp.spmv(x)
+    assert np.isclose(y[0], x[1:].sum(), rtol=1e-13) and np.array_equal(y[1:], np.full(n - 1, x[0]))
+    a, b, _, _, _ = grp.lanczos(np.ones(n), 4, want_q=False)
+    assert abs(a[0] - float(al)) <= 1e-14 * float(al) and abs(b[0] - float(be2) ** 0.5) <= 1e-13 * float(be2) ** 0.5
+    grp.close()
     # a "double star" (two centres sharing all leaves) + a clique of the first 300 vertices: rows that are heavy both
     # in staged and in blocked columns, many equal rows inside one 64-entry step (replica slots)
     m = 40000
