@@ -432,8 +432,9 @@ int lzx_graph_prepare(lzx_ctx *c)
 
     // ---- 4. upload tables, fill column codes ----
     PREP(dev_alloc(&c->d_slice_off, c->n_slices)); PREP(dev_alloc(&c->d_slice_w, c->n_slices));
-    PREP(dev_alloc(&c->d_sell_cols, c->sell_elems + 4));
-    PREP(dev_alloc(&c->d_long_cols, c->long_elems + 4));
+    // + 1 KiB: the SpMV's pipelined loads read one (clamped) packet row past a zero-width last slice / short item
+    PREP(dev_alloc(&c->d_sell_cols, c->sell_elems + 1024));
+    PREP(dev_alloc(&c->d_long_cols, c->long_elems + 1024));
     PREP(dev_alloc(&c->d_item_beg, c->n_items)); PREP(dev_alloc(&c->d_item_len, c->n_items));
     PREP(dev_alloc(&c->d_item_first, (u64)c->n_long64 + 1));
     PREP(dev_alloc(&c->d_long_partial, c->n_items));

@@ -61,14 +61,24 @@ struct SpmvArgs {
 };
 
 // Column code c: c < hub -> value staged in LDS slot c; otherwise x[c - hub].
-template <bool HUB>
+// HUB: 0 = nothing staged, 1 = both kinds of code, 2 = staged codes only (the other entries went to the blocked
+// passes): no global gather is compiled in, so the summing loops wait on LDS alone and never drain the index prefetch.
+template <int HUB>
 __device__ __forceinline__ double gather(u32 c, const double *__restrict__ x, const double *hubv, u32 hub)
 {
+    if (HUB == 2) return hubv[c];
     if (HUB) {
         if (c < hub) return hubv[c];
         return x[c - hub];
     }
     return x[c];
+}
+
+// value held by lane l (wave-uniform l) of a per-lane register
+__device__ __forceinline__ u32 lane_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ u64 lane_u64(u64 v, u32 l)
+{
+    return ((u64)lane_u32((u32)(v >> 32), l) << 32) | lane_u32((u32)v, l);
 }
 
 template <bool NT>
@@ -85,14 +95,15 @@ __device__ __forceinline__ uint4 load_idx4(const uint4 *p)
     return *p;
 }
 
-template <bool HUB, bool NT>
+template <int HUB, bool NT>
 __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *hubv = lds;
     double *wsum = lds + a.hub;  // 16 doubles behind the staged entries
 
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 
     if (HUB) {
         // Stage x of the `hub` highest-degree vertices once per workgroup (coalesced at world == 1;
@@ -105,94 +116,88 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
     }
 
     const u32 waves = gridDim.x * (LZX_SPMV_BLOCK / 64);
-    const u32 w0 = blockIdx.x * (LZX_SPMV_BLOCK / 64) + wv;
+    const u32 w0 = blockIdx.x * (LZX_SPMV_BLOCK / 64) + wv;   // scalar: wv came through readfirstlane
 
-    // Both loops below are three-stage software pipelines over the wavefront's units (unit i = w0 + i * waves):
-    // while unit i is summed, the index packets of unit i+1 are in flight and the descriptor of unit i+2 is being
-    // fetched.  Without it every unit pays two dependent memory round trips (descriptor, then packets) and, after
-    // the hub split leaves most units only a few packets long, the kernel is bound by those latencies, not by
-    // bandwidth (measured: 0.25 ms for 0.63 GB of indices on the 10 M-vertex graph).
-    // Units are dealt to wavefronts round-robin: neighbouring wavefronts stream neighbouring memory, and because
-    // widths fall monotonically (and are capped by the split-row threshold) every wavefront gets the same work.
+    // Units (split-row items, then 64-row slices) are dealt to wavefronts round-robin, unit i of a wavefront being
+    // w0 + i * waves: neighbouring wavefronts stream neighbouring memory, and because widths fall monotonically
+    // (and are capped by the split-row threshold) every wavefront gets the same work.
+    // Both loops are software pipelines built so that hipcc can wait with exact vmcnt(N) counts; after the hub
+    // split leaves most units only a few packets long the kernel is otherwise bound by memory round trips, not by
+    // bandwidth (measured 0.25 ms for 0.63 GB of indices on the 10 M-vertex graph).  Three rules:
+    //   * descriptors: one load fetches the descriptors of the wavefront's next 64 units, one per lane; each unit
+    //     then reads its own with v_readlane, so no unit waits for a descriptor round trip;
+    //   * packets: the first packets of unit i+1 are in flight while unit i is summed, in two register sets used
+    //     alternately (a rotation by register moves would have to wait for the loads it moves);
+    //   * every pipelined load is issued unconditionally from a clamped, always valid address: loads under `if`s
+    //     make the number in flight unknown to the compiler, which then drains the queue (vmcnt(0)) at every use.
 
     // ---- split rows: one wavefront sums one item of <= LZX_ITEM entries, lanes striding 16-byte index
     //      packets; the item totals are combined in row order by k_long_finish.
     {
-        u32 it = w0;
-        bool h0 = it < a.n_items, h1 = it + waves < a.n_items;
-        u64 beg0 = 0, beg1 = 0;
-        u32 len0 = 0, len1 = 0;
-        if (h0) { beg0 = a.item_beg[it]; len0 = a.item_len[it]; }
-        if (h1) { beg1 = a.item_beg[it + waves]; len1 = a.item_len[it + waves]; }
-        uint4 pk0 = make_uint4(0, 0, 0, 0), pk1 = make_uint4(0, 0, 0, 0);
-        if (h0) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + beg0);
-            const u32 packets = len0 >> 2;
-            if (lane < packets) pk0 = load_idx4<NT>(p + lane);
-            if (lane + 64 < packets) pk1 = load_idx4<NT>(p + lane + 64);
-        }
-        while (h0) {
-            // stage A: descriptor of item i+2
-            const bool h2 = it + 2 * waves < a.n_items;
-            u64 beg2 = 0;
-            u32 len2 = 0;
-            if (h2) { beg2 = a.item_beg[it + 2 * waves]; len2 = a.item_len[it + 2 * waves]; }
-            // stage B: first two packets per lane of item i+1
-            uint4 nk0 = make_uint4(0, 0, 0, 0), nk1 = make_uint4(0, 0, 0, 0);
-            if (h1) {
-                const uint4 *pn = reinterpret_cast<const uint4 *>(a.long_cols + beg1);
-                const u32 pkn = len1 >> 2;
-                if (lane < pkn) nk0 = load_idx4<NT>(pn + lane);
-                if (lane + 64 < pkn) nk1 = load_idx4<NT>(pn + lane + 64);
+        const u32 mine = a.n_items > w0 ? (a.n_items - w0 + waves - 1) / waves : 0;
+        for (u32 base = 0; base < mine; base += 64) {
+            const u32 cnt = mine - base < 64 ? mine - base : 64;
+            const u32 di = w0 + (base + (lane < cnt ? lane : 0)) * waves;
+            const u64 d_beg = a.item_beg[di];
+            const u32 d_pk = a.item_len[di] >> 2;
+            auto issue = [&](u32 j, uint4 &k0, uint4 &k1) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + lane_u64(d_beg, j));
+                const u32 packets = lane_u32(d_pk, j);
+                k0 = load_idx4<NT>(p + (lane < packets ? lane : 0));
+                k1 = load_idx4<NT>(p + (lane + 64 < packets ? lane + 64 : 0));
+            };
+            auto consume = [&](u32 j, const uint4 &k0, const uint4 &k1) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + lane_u64(d_beg, j));
+                const u32 packets = lane_u32(d_pk, j);
+                double acc = 0.0;
+                if (lane < packets) {
+                    const double x0 = gather<HUB>(k0.x, a.x, hubv, a.hub);
+                    const double x1 = gather<HUB>(k0.y, a.x, hubv, a.hub);
+                    const double x2 = gather<HUB>(k0.z, a.x, hubv, a.hub);
+                    const double x3 = gather<HUB>(k0.w, a.x, hubv, a.hub);
+                    acc += x0; acc += x1; acc += x2; acc += x3;
+                }
+                if (lane + 64 < packets) {
+                    const double x0 = gather<HUB>(k1.x, a.x, hubv, a.hub);
+                    const double x1 = gather<HUB>(k1.y, a.x, hubv, a.hub);
+                    const double x2 = gather<HUB>(k1.z, a.x, hubv, a.hub);
+                    const double x3 = gather<HUB>(k1.w, a.x, hubv, a.hub);
+                    acc += x0; acc += x1; acc += x2; acc += x3;
+                }
+                u32 q = lane + 128;
+                for (; q + 64 < packets; q += 128) {
+                    const uint4 c = load_idx4<NT>(p + q), e = load_idx4<NT>(p + q + 64);
+                    const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
+                    const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
+                    const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
+                    const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
+                    const double x4 = gather<HUB>(e.x, a.x, hubv, a.hub);
+                    const double x5 = gather<HUB>(e.y, a.x, hubv, a.hub);
+                    const double x6 = gather<HUB>(e.z, a.x, hubv, a.hub);
+                    const double x7 = gather<HUB>(e.w, a.x, hubv, a.hub);
+                    acc += x0; acc += x1; acc += x2; acc += x3;
+                    acc += x4; acc += x5; acc += x6; acc += x7;
+                }
+                for (; q < packets; q += 64) {
+                    const uint4 c = load_idx4<NT>(p + q);
+                    const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
+                    const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
+                    const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
+                    const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
+                    acc += x0; acc += x1; acc += x2; acc += x3;
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) a.long_partial[w0 + (base + j) * waves] = acc;
+            };
+            uint4 a0, a1, b0, b1;
+            issue(0, a0, a1);
+            for (u32 j = 0; j < cnt; j += 2) {
+                issue(j + 1 < cnt ? j + 1 : j, b0, b1);
+                consume(j, a0, a1);
+                if (j + 1 >= cnt) break;
+                issue(j + 2 < cnt ? j + 2 : j + 1, a0, a1);
+                consume(j + 1, b0, b1);
             }
-            // stage C: sum item i
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + beg0);
-            const u32 packets = len0 >> 2;
-            double acc = 0.0;
-            if (lane < packets) {
-                const double x0 = gather<HUB>(pk0.x, a.x, hubv, a.hub);
-                const double x1 = gather<HUB>(pk0.y, a.x, hubv, a.hub);
-                const double x2 = gather<HUB>(pk0.z, a.x, hubv, a.hub);
-                const double x3 = gather<HUB>(pk0.w, a.x, hubv, a.hub);
-                acc += x0; acc += x1; acc += x2; acc += x3;
-            }
-            if (lane + 64 < packets) {
-                const double x0 = gather<HUB>(pk1.x, a.x, hubv, a.hub);
-                const double x1 = gather<HUB>(pk1.y, a.x, hubv, a.hub);
-                const double x2 = gather<HUB>(pk1.z, a.x, hubv, a.hub);
-                const double x3 = gather<HUB>(pk1.w, a.x, hubv, a.hub);
-                acc += x0; acc += x1; acc += x2; acc += x3;
-            }
-            u32 q = lane + 128;
-            for (; q + 64 < packets; q += 128) {
-                const uint4 c = load_idx4<NT>(p + q), e = load_idx4<NT>(p + q + 64);
-                const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
-                const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
-                const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
-                const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
-                const double x4 = gather<HUB>(e.x, a.x, hubv, a.hub);
-                const double x5 = gather<HUB>(e.y, a.x, hubv, a.hub);
-                const double x6 = gather<HUB>(e.z, a.x, hubv, a.hub);
-                const double x7 = gather<HUB>(e.w, a.x, hubv, a.hub);
-                acc += x0; acc += x1; acc += x2; acc += x3;
-                acc += x4; acc += x5; acc += x6; acc += x7;
-            }
-            for (; q < packets; q += 64) {
-                const uint4 c = load_idx4<NT>(p + q);
-                const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
-                const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
-                const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
-                const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
-                acc += x0; acc += x1; acc += x2; acc += x3;
-            }
-            acc = wave_sum(acc);
-            if (lane == 0) a.long_partial[it] = acc;
-            // rotate
-            it += waves;
-            h0 = h1; h1 = h2;
-            beg0 = beg1; len0 = len1;
-            beg1 = beg2; len1 = len2;
-            pk0 = nk0; pk1 = nk1;
         }
     }
 
@@ -201,85 +206,70 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
     //      reference's spMV (serial/lib/SPMV.cc:24-27), so these rows come out bit-identical to it.
     double dot = 0.0;
     {
-        u32 s = w0;
-        bool h0 = s < a.n_slices, h1 = s + waves < a.n_slices;
-        u64 off0 = 0, off1 = 0;
-        u32 st0 = 0, st1 = 0;   // packets per lane
-        if (h0) { off0 = a.slice_off[s]; st0 = a.slice_w[s] >> 2; }
-        if (h1) { off1 = a.slice_off[s + waves]; st1 = a.slice_w[s + waves] >> 2; }
-        uint4 pf[4];
+        const u32 mine = a.n_slices > w0 ? (a.n_slices - w0 + waves - 1) / waves : 0;
+        for (u32 base = 0; base < mine; base += 64) {
+            const u32 cnt = mine - base < 64 ? mine - base : 64;
+            const u32 di = w0 + (base + (lane < cnt ? lane : 0)) * waves;
+            const u64 d_off = a.slice_off[di];
+            const u32 d_st = a.slice_w[di] >> 2;   // packets per lane
+            auto issue = [&](u32 j, uint4 (&f)[4], double &qrow) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + lane_u64(d_off, j)) + lane;
+                const u32 st = lane_u32(d_st, j);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pf[u] = make_uint4(0, 0, 0, 0);
-        if (h0) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + off0) + lane;
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if ((u32)u < st0) pf[u] = load_idx4<NT>(p + (size_t)u * 64);
-        }
-        while (h0) {
-            // stage A: descriptor of slice i+2
-            const bool h2 = s + 2 * waves < a.n_slices;
-            u64 off2 = 0;
-            u32 st2 = 0;
-            if (h2) { off2 = a.slice_off[s + 2 * waves]; st2 = a.slice_w[s + 2 * waves] >> 2; }
-            // stage B: first four packets of slice i+1
-            uint4 nf[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) nf[u] = make_uint4(0, 0, 0, 0);
-            if (h1) {
-                const uint4 *pn = reinterpret_cast<const uint4 *>(a.sell_cols + off1) + lane;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if ((u32)u < st1) nf[u] = load_idx4<NT>(pn + (size_t)u * 64);
-            }
-            // stage C: sum slice i
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + off0) + lane;
-            const u32 row = a.row0 + s * 64 + lane;
-            const double qrow = a.q_loc[row];
-            double acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if ((u32)u < st0) {
-                    const double x0 = gather<HUB>(pf[u].x, a.x, hubv, a.hub);
-                    const double x1 = gather<HUB>(pf[u].y, a.x, hubv, a.hub);
-                    const double x2 = gather<HUB>(pf[u].z, a.x, hubv, a.hub);
-                    const double x3 = gather<HUB>(pf[u].w, a.x, hubv, a.hub);
-                    acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
-                }
-            }
-            u32 i = 4;
-            for (; i + 4 <= st0; i += 4) {
-                uint4 c[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(p + (size_t)(i + u) * 64);
-                double xv[16];
+                for (int u = 0; u < 4; ++u) f[u] = load_idx4<NT>(p + (size_t)((u32)u < st ? u : 0) * 64);
+                qrow = a.q_loc[a.row0 + (w0 + (base + j) * waves) * 64 + lane];
+            };
+            auto consume = [&](u32 j, const uint4 (&f)[4], double qrow) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + lane_u64(d_off, j)) + lane;
+                const u32 st = lane_u32(d_st, j);
+                double acc = 0.0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    xv[4 * u + 0] = gather<HUB>(c[u].x, a.x, hubv, a.hub);
-                    xv[4 * u + 1] = gather<HUB>(c[u].y, a.x, hubv, a.hub);
-                    xv[4 * u + 2] = gather<HUB>(c[u].z, a.x, hubv, a.hub);
-                    xv[4 * u + 3] = gather<HUB>(c[u].w, a.x, hubv, a.hub);
+                    if ((u32)u < st) {
+                        const double x0 = gather<HUB>(f[u].x, a.x, hubv, a.hub);
+                        const double x1 = gather<HUB>(f[u].y, a.x, hubv, a.hub);
+                        const double x2 = gather<HUB>(f[u].z, a.x, hubv, a.hub);
+                        const double x3 = gather<HUB>(f[u].w, a.x, hubv, a.hub);
+                        acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
+                    }
                 }
+                u32 i = 4;
+                for (; i + 4 <= st; i += 4) {
+                    uint4 c[4];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc += xv[u];
-            }
-            for (; i < st0; ++i) {
-                const uint4 c0 = load_idx4<NT>(p + (size_t)i * 64);
-                const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
-                const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
-                const double x2 = gather<HUB>(c0.z, a.x, hubv, a.hub);
-                const double x3 = gather<HUB>(c0.w, a.x, hubv, a.hub);
-                acc += x0; acc += x1; acc += x2; acc += x3;
-            }
-            a.v[row] = acc;
-            dot += acc * qrow;
-            // rotate
-            s += waves;
-            h0 = h1; h1 = h2;
-            off0 = off1; st0 = st1;
-            off1 = off2; st1 = st2;
+                    for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(p + (size_t)(i + u) * 64);
+                    double xv[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pf[u] = nf[u];
+                    for (int u = 0; u < 4; ++u) {
+                        xv[4 * u + 0] = gather<HUB>(c[u].x, a.x, hubv, a.hub);
+                        xv[4 * u + 1] = gather<HUB>(c[u].y, a.x, hubv, a.hub);
+                        xv[4 * u + 2] = gather<HUB>(c[u].z, a.x, hubv, a.hub);
+                        xv[4 * u + 3] = gather<HUB>(c[u].w, a.x, hubv, a.hub);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += xv[u];
+                }
+                for (; i < st; ++i) {
+                    const uint4 c0 = load_idx4<NT>(p + (size_t)i * 64);
+                    const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
+                    const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
+                    const double x2 = gather<HUB>(c0.z, a.x, hubv, a.hub);
+                    const double x3 = gather<HUB>(c0.w, a.x, hubv, a.hub);
+                    acc += x0; acc += x1; acc += x2; acc += x3;
+                }
+                a.v[a.row0 + (w0 + (base + j) * waves) * 64 + lane] = acc;
+                dot += acc * qrow;
+            };
+            uint4 fa[4], fb[4];
+            double qa, qb;
+            issue(0, fa, qa);
+            for (u32 j = 0; j < cnt; j += 2) {
+                issue(j + 1 < cnt ? j + 1 : j, fb, qb);
+                consume(j, fa, qa);
+                if (j + 1 >= cnt) break;
+                issue(j + 2 < cnt ? j + 2 : j + 1, fa, qa);
+                consume(j + 1, fb, qb);
+            }
         }
     }
 
@@ -426,7 +416,7 @@ static u32 vec_grid(const lzx_ctx *c)
 
 u32 lzx_spmv_partials(const lzx_ctx *c) { return c->spmv_grid + c->fin_grid + lzx_pb_partials(c); }
 
-template <bool HUB, bool NT>
+template <int HUB, bool NT>
 static int launch_spmv_t(lzx_ctx *c, const SpmvArgs &a)
 {
     auto kern = k_spmv<HUB, NT>;
@@ -459,12 +449,15 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.xs0 = c->xs0;
     const bool nt = c->nt_opt > 0;
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[0], c->stream));
-    if (c->hub > 0) {
-        if (nt) LZX_TRY((launch_spmv_t<true, true>(c, a)));
-        else    LZX_TRY((launch_spmv_t<true, false>(c, a)));
+    if (c->hub > 0 && c->pb) {
+        if (nt) LZX_TRY((launch_spmv_t<2, true>(c, a)));
+        else    LZX_TRY((launch_spmv_t<2, false>(c, a)));
+    } else if (c->hub > 0) {
+        if (nt) LZX_TRY((launch_spmv_t<1, true>(c, a)));
+        else    LZX_TRY((launch_spmv_t<1, false>(c, a)));
     } else {
-        if (nt) LZX_TRY((launch_spmv_t<false, true>(c, a)));
-        else    LZX_TRY((launch_spmv_t<false, false>(c, a)));
+        if (nt) LZX_TRY((launch_spmv_t<0, true>(c, a)));
+        else    LZX_TRY((launch_spmv_t<0, false>(c, a)));
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[1], c->stream));
     if (c->fin_grid > 0) {

@@ -46,6 +46,8 @@ if __name__ == "__main__":
     if "pb" in sets:
         opts = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=8192),
                 dict(propagation_blocking=1, hub_entries=19000)]
+    if "hubk" in sets:
+        opts = [dict(), dict(propagation_blocking=0), dict(phase_mask=1), dict(phase_mask=2)]
     if "phase" in sets:
         opts = [dict(phase_mask=1), dict(phase_mask=2), dict(phase_mask=1, hub_entries=0), dict(phase_mask=2, hub_entries=0),
                 dict(long_row=256), dict(long_row=4096), dict(long_row=65536)]
