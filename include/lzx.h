@@ -68,6 +68,9 @@ typedef struct lzx_graph_info {
     uint64_t exchange_slice;  /* doubles each rank contributes to the per-iteration all-gather */
     uint32_t hub_entries; /* x entries staged in LDS per workgroup               */
     uint32_t world, rank;
+    uint32_t reserved_;
+    uint64_t pb_values;   /* values the blocked scatter passes hand to the gather pass per SpMV (padding included) */
+    uint64_t pb_reduced_entries; /* of pb_entries: entries of the reduced bands, which travel as partial row sums */
 } lzx_graph_info;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -170,7 +173,7 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  *                           rows are summed in the reference's order and come out bit-identical to serial/
  *   "overlap_exchange"      several ranks: 1 / 0 allow / forbid the two-chunk all-gather that overlaps the blocked
  *                           SpMV (default: allowed)
- *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align"
+ *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce"
  *                           experiment knobs behind DESIGN.md's tuning log (tools/perf_probe.py)               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);
 

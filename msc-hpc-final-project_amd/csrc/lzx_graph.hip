@@ -720,6 +720,9 @@ extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
     o->sell_padded = c->sell_elems + c->long_elems;
     o->hub_entries = c->hub_real;
     o->pb_entries = c->pb ? c->pb_entries : 0;
+    o->pb_values = c->pb ? c->pb_values : 0;
+    o->pb_reduced_entries = c->pb ? c->pbr_entries : 0;
+    o->reserved_ = 0;
     o->active_vertices = c->n_active;
     o->exchange_slice = c->world > 1 ? c->xs : 0;
     o->world = (uint32_t)c->world;

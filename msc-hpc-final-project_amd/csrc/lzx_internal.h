@@ -58,6 +58,10 @@ static constexpr u32 LZX_PB_UNIT = 1u << 18;
 static constexpr u32 LZX_PB_TARGET = 32768;   // entries per row band = per gather wavefront
 static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
+// reduced bands (partial row sums instead of single values cross the two passes)
+static constexpr u32 LZX_PBR_CHUNK = 8;       // consecutive entries one lane adds up (one 16-byte load)
+static constexpr u32 LZX_PBR_STEP = 512;      // entries per wavefront step; runs of reduced bands are padded to whole steps
+static constexpr u32 LZX_PBR_MIN_RUN = 384;   // a band is reduced when its (row band, column band) runs average this many entries
 
 struct lzx_ctx {
     int device = 0;
@@ -109,6 +113,7 @@ struct lzx_ctx {
     u32 pb_units0 = 0;                 // scatter units whose column band lies wholly in chunk 0
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
+    int64_t pb_reduce_opt = -1;        // reduced bands: -1 auto (on), 0 off, > 1: minimum average run length
     int64_t long_row_opt = -1;         // split-row threshold override
     int64_t phase_mask_opt = 3;        // debug: 1 = split rows only, 2 = body only
 
@@ -144,10 +149,17 @@ struct lzx_ctx {
     u32 *d_pb_row0 = nullptr;          // [pb_nr + 1] first local row of each row band
     u32 *d_pb_rep = nullptr;           // [pb_nr] LDS slots per row in that band's y tile
     u32 *d_pb_items = nullptr;         // [pb_n_items][4] row band, begin, end (gather order), slot or ~0
-    u32 *d_pb_multi = nullptr;         // [pb_n_multi][3] row, first slot, slots: rows cut into several items
+    u32 *d_pb_multi = nullptr;         // [pb_n_multi][4] row, first slot, items, slot stride: rows of bands cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;
+    u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)
+    u64 pbr_entries = 0;               // entries of the reduced bands
+    u64 pb_val_offset = 0;             // first value of the plain bands in d_pb_val (the reduced bands' pieces come first)
+    uint4 *d_pbr_code = nullptr;       // [pbr_steps][64] scatter order: 8 x (column in band | piece-end flag) per lane
+    u32 *d_pbr_base = nullptr;         // [pbr_steps] first value slot of the step
+    u32 *d_pbr_unit = nullptr;         // [pbr_units][3] band, first step, last step
+    u32 pbr_steps = 0, pbr_units = 0, pbr_units0 = 0;
 
     // vectors and scalars
     double *d_v = nullptr;             // [ldq]

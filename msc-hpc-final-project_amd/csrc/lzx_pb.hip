@@ -17,7 +17,16 @@
 //       touches the tile, so additions happen in program order.  The tile is then folded (rep replicas per row),
 //       added to v, and the wave forms its share of alpha = v . q.  A single row with more than 2 targets of
 //       entries is cut into items whose totals k_pb_finish adds in order.
-// All tables are static (built once per graph by lzx_pb_prepare: two radix sorts and a few scans).
+//   reduced scatter (k_pbr_scatter): the first row bands -- the high-degree rows, where a row has many entries in
+//       one column band (on the 10 M-vertex R-MAT graph the 222 M blocked entries of rows with degree >= 128 form
+//       only 37 M distinct (row, column band) pairs) -- do not pass single x values to the gather pass but partial
+//       row sums.  Their (row band, column band) runs are cut into steps of 512 entries; lane l of a wavefront takes
+//       8 consecutive entries (one 16-byte load of 15-bit columns-in-band, bit 15 = "last entry of its row in this
+//       lane"), adds them up from LDS and emits one value per piece.  Pieces that close at entry e of their lane form
+//       plane e of the step and are written lane-compacted (ballot + mbcnt), so every store instruction writes one
+//       contiguous stretch and no prefix scan is needed; the matching row slots are static.  Several pieces of one
+//       row are simply added by the gather pass, like single entries are.
+// All tables are static (built once per graph by lzx_pb_prepare: radix sorts and a few scans).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -215,6 +224,85 @@ __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *
     lslot[p] = (uint16_t)(r * rep + (occ[p] % rep));
 }
 
+
+// ---- reduced bands: build ------------------------------------------------------------------------------------
+// entry i of the (row band, column band, row, column)-sorted keys -> padded position (runs padded to whole steps):
+// code = column in band | 0x8000 on the last entry of a piece (same row, same 8-entry lane chunk), row in band,
+// and the column band of every step
+__global__ void k_pbr_place(const u64 *keys, const u32 *runid_incl, const u32 *runstart, const u32 *pstart, u64 count,
+                            uint16_t *rcode, uint16_t *rrow, uint16_t *step_cband)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u32 r = runid_incl[i] - 1;
+    const u32 off = (u32)i - runstart[r];
+    const u32 pos = pstart[r] + off;
+    const u64 k = keys[i];
+    const u32 lrow = (u32)((k >> 14) & 0x3ffu);
+    const bool last = (off & (LZX_PBR_CHUNK - 1)) == LZX_PBR_CHUNK - 1 || i + 1 == count || runid_incl[i + 1] - 1 != r ||
+                      (u32)((keys[i + 1] >> 14) & 0x3ffu) != lrow;
+    rcode[pos] = (uint16_t)((k & 0x3fffu) | (last ? 0x8000u : 0u));
+    rrow[pos] = (uint16_t)lrow;
+    if ((off & (LZX_PBR_STEP - 1)) == 0) step_cband[pos / LZX_PBR_STEP] = (uint16_t)((k >> 24) & 0xffffu);
+}
+
+// first step of every reduced band (a band starts a run, a run starts a step)
+__global__ void k_pbr_band_step(const u32 *rstart, const u32 *runid_incl, const u32 *pstart, u32 nred, u64 count,
+                                u32 nsteps, u32 *band_step)
+{
+    const u32 R = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R > nred) return;
+    const u32 i = rstart[R];
+    band_step[R] = i < count ? pstart[runid_incl[i] - 1] / LZX_PBR_STEP : nsteps;
+}
+
+__device__ __forceinline__ u32 pbr_flag(const uint4 &c, int e)
+{
+    const u32 w = (e >> 1) == 0 ? c.x : (e >> 1) == 1 ? c.y : (e >> 1) == 2 ? c.z : c.w;
+    return (w >> ((e & 1) ? 31 : 15)) & 1u;
+}
+__device__ __forceinline__ u32 pbr_half(const uint4 &c, int e)
+{
+    const u32 w = (e >> 1) == 0 ? c.x : (e >> 1) == 1 ? c.y : (e >> 1) == 2 ? c.z : c.w;
+    return (e & 1) ? (w >> 16) : (w & 0xffffu);
+}
+__device__ __forceinline__ u32 lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+// pieces per step
+__global__ void __launch_bounds__(64) k_pbr_count(const uint4 *rcode, u32 *cnt)
+{
+    const uint4 c = rcode[(size_t)blockIdx.x * 64 + threadIdx.x];
+    u32 n = __popc(c.x & 0x80008000u) + __popc(c.y & 0x80008000u) + __popc(c.z & 0x80008000u) + __popc(c.w & 0x80008000u);
+    for (int o = 32; o > 0; o >>= 1) n += (u32)__shfl_xor((int)n, o, 64);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = n;
+}
+
+// row (in band) of every piece, at the position k_pbr_scatter writes the piece to
+__global__ void __launch_bounds__(64) k_pbr_rows(const uint4 *rcode, const uint4 *rrow, const u32 *step_base, uint16_t *prow)
+{
+    const uint4 c = rcode[(size_t)blockIdx.x * 64 + threadIdx.x];
+    const uint4 r = rrow[(size_t)blockIdx.x * 64 + threadIdx.x];
+    u32 base = step_base[blockIdx.x];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool f = pbr_flag(c, e) != 0;
+        const unsigned long long m = __ballot(f);
+        if (f) prow[base + lanes_below(m)] = (uint16_t)pbr_half(r, e);
+        base += (u32)__popcll(m);
+    }
+}
+
+// scatter order of the steps: step j of the order is step ssorted[j] of the gather (row band major) order
+__global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint4 *rcode, const u32 *step_base, uint4 *scode, u32 *sbase)
+{
+    const u32 s = ssorted[blockIdx.x];
+    scode[(size_t)blockIdx.x * 64 + threadIdx.x] = rcode[(size_t)s * 64 + threadIdx.x];
+    if (threadIdx.x == 0) sbase[blockIdx.x] = step_base[s];
+}
+
 // ---- the per-iteration kernels --------------------------------------------------------------------------------
 // unit = {column band, first quad, last quad} in scatter order.  Each wavefront walks its own contiguous share of the
 // unit 64 quads at a time (lane = consecutive quad): contiguous loads, and 32-byte-per-lane stores that are
@@ -268,6 +356,54 @@ k_pb_scatter(const u32 *unit, const uint2 *q_lcol, const u32 *q_dst, const doubl
     }
 }
 
+// Reduced scatter: unit = {column band, first step, last step}; wavefront w of the workgroup takes steps w, w+16, ...
+// of the unit, four steps' loads in flight.
+__global__ void __launch_bounds__(1024)
+k_pbr_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const double *__restrict__ x, u64 xlen, double *val)
+{
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // LZX_PB_CB staged values + a zero for padding
+    const u32 band = unit[3 * blockIdx.x], beg = unit[3 * blockIdx.x + 1], end = unit[3 * blockIdx.x + 2];
+    const u64 base = (u64)band * LZX_PB_CB;
+    for (u32 j = threadIdx.x; j < LZX_PB_CB + 2; j += 1024) {
+        const u64 p = base + j;
+        tile[j] = (j < LZX_PB_CB && p < xlen) ? x[p] : 0.0;
+    }
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    auto body = [&](const uint4 &c, u32 pos) {
+        double xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = tile[pbr_half(c, e) & 0x7fffu];
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool f = pbr_flag(c, e) != 0;
+            s += xv[e];
+            const unsigned long long m = __ballot(f);
+            if (f) {
+                val[pos + lanes_below(m)] = s;
+                s = 0.0;
+            }
+            pos += (u32)__popcll(m);
+        }
+    };
+    constexpr u32 W = 1024 / 64;
+    u32 s = beg + wv;
+    for (; s + 3 * W < end; s += 4 * W) {
+        uint4 c[4];
+        u32 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+            b[u] = sbase[s + u * W];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) body(c[u], b[u]);
+    }
+    for (; s < end; s += W) body(scode[(size_t)s * 64 + lane], sbase[s]);
+}
+
 __device__ __forceinline__ double wave_sum_pb(double v)
 {
 #pragma unroll
@@ -275,9 +411,9 @@ __device__ __forceinline__ double wave_sum_pb(double v)
     return v;
 }
 
-// item table entry: {row band, begin, end, slot} in padded gather positions; slot == 0xffffffff: the item is its
-// band's only one and adds straight into v; otherwise it is one of several items of a single-row band and leaves
-// its total in part[slot].
+// item table entry: {row band, begin, end, slot} in gather positions; slot == 0xffffffff: the item is its band's
+// only one and adds straight into v; otherwise it is one of several items of its band and leaves its per-row totals
+// in part[slot + row in band] for k_pb_finish.
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
 k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *band_rep, const uint16_t *lslot,
             const double *val, double *v, const double *__restrict__ q_loc, double *part, double *partials)
@@ -335,11 +471,19 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
         }
         for (; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
         __builtin_amdgcn_wave_barrier();
-        for (u32 j = lane; j < rows; j += 64) {
-            double y = 0.0;
-            for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
-            v[row0 + j] += y;
-            dot += y * q_loc[row0 + j];
+        if (item.w == 0xffffffffu) {
+            for (u32 j = lane; j < rows; j += 64) {
+                double y = 0.0;
+                for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                v[row0 + j] += y;
+                dot += y * q_loc[row0 + j];
+            }
+        } else {
+            for (u32 j = lane; j < rows; j += 64) {
+                double y = 0.0;
+                for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                part[item.w + j] = y;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -353,18 +497,19 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     }
 }
 
-// rows cut into several items: v[row] += item totals in item order; alpha partials for those rows
+// rows of bands cut into several items: v[row] += item totals in item order; alpha partials for those rows
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
-k_pb_finish(const u32 *multi /*[n][3]: row, first slot, slots*/, u32 n_multi, const double *part, double *v,
+k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32 n_multi, const double *part, double *v,
             const double *q_loc, double *partials)
 {
     __shared__ double sh[4];
     const u32 t = blockIdx.x * LZX_VEC_BLOCK + threadIdx.x;
     double dot = 0.0;
     if (t < n_multi) {
-        const u32 row = multi[3 * t], first = multi[3 * t + 1], cnt = multi[3 * t + 2];
+        const uint4 m = multi[t];
+        const u32 row = m.x;
         double s = 0.0;
-        for (u32 k = 0; k < cnt; ++k) s += part[first + k];
+        for (u32 k = 0; k < m.z; ++k) s += part[m.y + (size_t)k * m.w];
         v[row] += s;
         dot = s * q_loc[row];
     }
@@ -401,31 +546,292 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_items);
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
+    pb_free(c->d_pbr_code);
+    pb_free(c->d_pbr_base);
+    pb_free(c->d_pbr_unit);
     c->pb = false;
-    c->pb_entries = 0;
-    c->pb_units = c->pb_nr = c->pb_gather_grid = c->pb_n_items = c->pb_n_multi = c->pb_finish_grid = 0;
+    c->pb_entries = c->pb_values = c->pbr_entries = c->pb_val_offset = 0;
+    c->pb_units = c->pb_units0 = c->pb_nr = c->pb_gather_grid = c->pb_n_items = c->pb_n_multi = c->pb_finish_grid = 0;
+    c->pbr_steps = c->pbr_units = c->pbr_units0 = 0;
 }
 
 u32 lzx_pb_partials(const lzx_ctx *c) { return c->pb ? c->pb_gather_grid + c->pb_finish_grid : 0; }
 
-int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, const u32 *d_deg_local,
-                   const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total)
+namespace {
+// ---- build helpers: every one leaves its temporaries to the caller's arena, which frees them on any exit ----------
+struct Arena {
+    std::vector<void *> ptrs;
+    template <typename T> int get(T **p, u64 count)
+    {
+        LZX_TRY(pb_alloc(p, count));
+        ptrs.push_back(*p);
+        return LZX_OK;
+    }
+    template <typename T> void drop(T *&p)
+    {
+        for (auto &q : ptrs)
+            if (q == p) q = nullptr;
+        pb_free(p);
+    }
+    ~Arena()
+    {
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+    }
+};
+#define GRID(n) dim3((u32)(((u64)(n) + 255) / 256)), dim3(256), 0, st
+
+int pb_sort_keys(hipStream_t st, u64 *in, u64 *out, u64 count)
+{
+    size_t tb = 0;
+    void *tmp = nullptr;
+    LZX_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, in, out, count, 0, 64, st));
+    LZX_HIP(hipMalloc(&tmp, tb ? tb : 16));
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tb, in, out, count, 0, 64, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    LZX_HIP(e);
+    return LZX_OK;
+}
+int pb_sort_pairs16(hipStream_t st, u32 *kin, u32 *kout, u32 *vin, u32 *vout, u64 count)
+{
+    size_t tb = 0;
+    void *tmp = nullptr;
+    LZX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, kin, kout, vin, vout, count, 0, 16, st));
+    LZX_HIP(hipMalloc(&tmp, tb ? tb : 16));
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, kin, kout, vin, vout, count, 0, 16, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    LZX_HIP(e);
+    return LZX_OK;
+}
+int pb_scan(hipStream_t st, bool inclusive, u32 *in, u32 *out, u64 count)
+{
+    size_t tb = 0;
+    void *tmp = nullptr;
+    if (inclusive) LZX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, in, out, count, st));
+    else LZX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, count, st));
+    LZX_HIP(hipMalloc(&tmp, tb ? tb : 16));
+    hipError_t e = inclusive ? hipcub::DeviceScan::InclusiveSum(tmp, tb, in, out, count, st)
+                             : hipcub::DeviceScan::ExclusiveSum(tmp, tb, in, out, count, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    LZX_HIP(e);
+    return LZX_OK;
+}
+
+// runs = maximal stretches of one (row band, column band) in sorted keys; each padded to a multiple of `align`
+struct Runs {
+    u32 *runid = nullptr, *runstart = nullptr, *pstart = nullptr;   // [count] inclusive run number; [nruns+1]; [nruns+1] padded start
+    u32 nruns = 0, total_pad = 0;
+};
+int pb_layout_runs(Arena &ar, hipStream_t st, const u64 *keys, u64 count, u32 align, Runs &r)
+{
+    u32 *head = nullptr, *padlen = nullptr;
+    LZX_TRY(ar.get(&head, count));
+    LZX_TRY(ar.get(&r.runid, count));
+    hipLaunchKernelGGL(k_pb_heads, GRID(count), keys, count, head);
+    LZX_TRY(pb_scan(st, true, head, r.runid, count));
+    LZX_HIP(hipMemcpy(&r.nruns, r.runid + (count - 1), sizeof(u32), hipMemcpyDeviceToHost));
+    LZX_TRY(ar.get(&r.runstart, (u64)r.nruns + 1));
+    LZX_TRY(ar.get(&padlen, (u64)r.nruns + 1));
+    LZX_TRY(ar.get(&r.pstart, (u64)r.nruns + 1));
+    hipLaunchKernelGGL(k_pb_runstarts, GRID(count), head, r.runid, count, r.runstart);
+    LZX_HIP(hipMemsetAsync(padlen + r.nruns, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_pb_padlen, GRID(r.nruns), r.runstart, r.nruns, count, align, padlen);
+    // 64-bit check of the padded total before the 32-bit scan
+    {
+        std::vector<u32> h((size_t)r.nruns);
+        LZX_HIP(hipMemcpyAsync(h.data(), padlen, sizeof(u32) * r.nruns, hipMemcpyDeviceToHost, st));
+        LZX_HIP(hipStreamSynchronize(st));
+        u64 sum = 0;
+        for (u32 v : h) sum += v;
+        if (sum >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu padded entries do not fit 32-bit slots", (unsigned long long)sum);
+    }
+    LZX_TRY(pb_scan(st, false, padlen, r.pstart, (u64)r.nruns + 1));
+    LZX_HIP(hipMemcpy(&r.total_pad, r.pstart + r.nruns, sizeof(u32), hipMemcpyDeviceToHost));
+    ar.drop(head);
+    ar.drop(padlen);
+    return LZX_OK;
+}
+
+// (column band, first, last) work units over something sorted by column band, at most `cap` things per unit;
+// units0 = how many of them (they are sorted by band) lie wholly inside chunk 0 of the exchange layout
+int pb_units(const lzx_ctx *c, hipStream_t st, const u32 *d_bstart, u32 nb, u32 cap, u32 **d_unit, u32 *n_units, u32 *n_units0)
+{
+    std::vector<u32> bstart((size_t)nb + 1), units;
+    LZX_HIP(hipMemcpyAsync(bstart.data(), d_bstart, sizeof(u32) * ((size_t)nb + 1), hipMemcpyDeviceToHost, st));
+    LZX_HIP(hipStreamSynchronize(st));
+    for (u32 b = 0; b < nb; ++b)
+        for (u32 s = bstart[b]; s < bstart[b + 1]; s += cap) {
+            units.push_back(b);
+            units.push_back(s);
+            units.push_back(std::min(bstart[b + 1], s + cap));
+        }
+    *n_units = (u32)(units.size() / 3);
+    *n_units0 = *n_units;
+    if (c->overlap) {
+        const u64 chunk0_end = (u64)c->world * c->xs0;
+        u32 u0 = 0;
+        while (u0 < *n_units && ((u64)units[3 * u0] + 1) * LZX_PB_CB <= chunk0_end) ++u0;
+        *n_units0 = u0;
+    }
+    LZX_TRY(pb_alloc(d_unit, units.size()));
+    if (!units.empty())
+        LZX_HIP(hipMemcpyAsync(*d_unit, units.data(), sizeof(u32) * units.size(), hipMemcpyHostToDevice, st));
+    LZX_HIP(hipStreamSynchronize(st));
+    return LZX_OK;
+}
+
+// Reduced bands [0, nred): keys[0, count) sorted.  Leaves the scatter tables in c, the row of every piece in
+// prow[0, *pieces) and the first value position of every reduced band (and the end) in band_pos[0 .. nred].
+int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nred, u32 nr, u32 nb, uint16_t *prow,
+                     std::vector<u32> &band_pos, u32 *pieces)
+{
+    Arena ar;
+    Runs runs;
+    LZX_TRY(pb_layout_runs(ar, st, keys, count, LZX_PBR_STEP, runs));
+    const u32 nsteps = runs.total_pad / LZX_PBR_STEP;
+    uint16_t *rcode = nullptr, *rrow = nullptr, *step_cband = nullptr;
+    LZX_TRY(ar.get(&rcode, (u64)runs.total_pad + 8));
+    LZX_TRY(ar.get(&rrow, (u64)runs.total_pad + 8));
+    LZX_TRY(ar.get(&step_cband, (u64)nsteps + 1));
+    hipLaunchKernelGGL(k_pb_fill16, GRID(runs.total_pad), rcode, runs.total_pad, (uint16_t)LZX_PB_CB);   // padding: the zero slot, no flag
+    hipLaunchKernelGGL(k_pb_fill16, GRID(runs.total_pad), rrow, runs.total_pad, (uint16_t)0xffffu);
+    hipLaunchKernelGGL(k_pbr_place, GRID(count), keys, runs.runid, runs.runstart, runs.pstart, count, rcode, rrow, step_cband);
+    // first step of each reduced band
+    u32 *rstart = nullptr, *band_step = nullptr;
+    LZX_TRY(ar.get(&rstart, (u64)nr + 1));
+    LZX_TRY(ar.get(&band_step, (u64)nred + 1));
+    hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), keys, count, 40u, nr, rstart);
+    hipLaunchKernelGGL(k_pbr_band_step, GRID(nred + 1), rstart, runs.runid, runs.pstart, nred, count, nsteps, band_step);
+    LZX_HIP(hipStreamSynchronize(st));
+    ar.drop(runs.runid); ar.drop(runs.runstart); ar.drop(runs.pstart); ar.drop(rstart);
+    // pieces per step -> first value slot of each step (gather order = step order here)
+    u32 *step_cnt = nullptr, *step_base = nullptr;
+    LZX_TRY(ar.get(&step_cnt, (u64)nsteps + 1));
+    LZX_TRY(ar.get(&step_base, (u64)nsteps + 1));
+    LZX_HIP(hipMemsetAsync(step_cnt + nsteps, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_pbr_count, dim3(nsteps), dim3(64), 0, st, reinterpret_cast<const uint4 *>(rcode), step_cnt);
+    LZX_TRY(pb_scan(st, false, step_cnt, step_base, (u64)nsteps + 1));
+    hipLaunchKernelGGL(k_pbr_rows, dim3(nsteps), dim3(64), 0, st, reinterpret_cast<const uint4 *>(rcode),
+                       reinterpret_cast<const uint4 *>(rrow), step_base, prow);
+    {
+        std::vector<u32> h_step((size_t)nred + 1), h_base((size_t)nsteps + 1);
+        LZX_HIP(hipMemcpyAsync(h_step.data(), band_step, sizeof(u32) * ((size_t)nred + 1), hipMemcpyDeviceToHost, st));
+        LZX_HIP(hipMemcpyAsync(h_base.data(), step_base, sizeof(u32) * ((size_t)nsteps + 1), hipMemcpyDeviceToHost, st));
+        LZX_HIP(hipStreamSynchronize(st));
+        band_pos.resize((size_t)nred + 1);
+        for (u32 R = 0; R <= nred; ++R) band_pos[R] = h_base[h_step[R]];
+        *pieces = h_base[nsteps];
+    }
+    ar.drop(rrow); ar.drop(step_cnt); ar.drop(band_step);
+    // scatter order: steps sorted (stably) by column band
+    u32 *skey = nullptr, *skey_s = nullptr, *sidx = nullptr, *ssorted = nullptr, *bstart = nullptr;
+    LZX_TRY(ar.get(&skey, nsteps)); LZX_TRY(ar.get(&skey_s, nsteps)); LZX_TRY(ar.get(&sidx, nsteps)); LZX_TRY(ar.get(&ssorted, nsteps));
+    hipLaunchKernelGGL(k_pb_iota_widen, GRID(nsteps), step_cband, nsteps, skey, sidx);
+    LZX_TRY(pb_sort_pairs16(st, skey, skey_s, sidx, ssorted, nsteps));
+    LZX_TRY(pb_alloc(&c->d_pbr_code, (u64)nsteps * 64 + 1));
+    LZX_TRY(pb_alloc(&c->d_pbr_base, (u64)nsteps + 1));
+    hipLaunchKernelGGL(k_pbr_steps, dim3(nsteps), dim3(64), 0, st, ssorted, reinterpret_cast<const uint4 *>(rcode), step_base,
+                       c->d_pbr_code, c->d_pbr_base);
+    LZX_TRY(ar.get(&bstart, (u64)nb + 1));
+    hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), skey_s, nsteps, nb, bstart);
+    LZX_TRY(pb_units(c, st, bstart, nb, LZX_PB_UNIT / LZX_PBR_STEP, &c->d_pbr_unit, &c->pbr_units, &c->pbr_units0));
+    c->pbr_steps = nsteps;
+    LZX_HIP(hipStreamSynchronize(st));
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+// Plain bands: keys[0, count) sorted (all of bands >= nred).  Leaves the quad scatter tables in c, the row of every
+// padded position in prow[0, *total_pad) and the first padded position of every band in band_pos[0 .. nr]
+// (relative to this part; bands < nred get 0).
+int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nr, u32 nb, uint16_t *prow,
+                   std::vector<u32> &band_pos, u32 *total_pad_out)
+{
+    Arena ar;
+    Runs runs;
+    const u32 run_align = (c->pb_align_opt == 8 || c->pb_align_opt == 16 || c->pb_align_opt == 4) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
+    LZX_TRY(pb_layout_runs(ar, st, keys, count, run_align, runs));
+    const u32 total_pad = runs.total_pad;
+    const u64 nquads = total_pad / 4;
+    // padded positions: row / column in band per position (0xffff / column "CB" = the zero behind the staged band
+    // for padding), column band per quad
+    uint16_t *plcol = nullptr, *qcband = nullptr;
+    u32 *pos = nullptr, *rstart = nullptr, *rstart_pad = nullptr;
+    LZX_TRY(ar.get(&plcol, (u64)total_pad + 8)); LZX_TRY(ar.get(&qcband, nquads + 2)); LZX_TRY(ar.get(&pos, count));
+    hipLaunchKernelGGL(k_pb_fill16, GRID(total_pad), plcol, total_pad, (uint16_t)LZX_PB_CB);
+    hipLaunchKernelGGL(k_pb_fill16, GRID(nquads + 2), qcband, nquads + 2, (uint16_t)0xffffu);   // all-padding quads: no band
+    hipLaunchKernelGGL(k_pb_place, GRID(count), keys, runs.runid, runs.runstart, runs.pstart, count, prow, plcol, qcband, pos);
+    LZX_TRY(ar.get(&rstart, (u64)nr + 1)); LZX_TRY(ar.get(&rstart_pad, (u64)nr + 1));
+    hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), keys, count, 40u, nr, rstart);
+    hipLaunchKernelGGL(k_pb_rstart_pad, GRID(nr + 1), rstart, pos, nr, count, total_pad, rstart_pad);
+    band_pos.resize((size_t)nr + 1);
+    LZX_HIP(hipMemcpyAsync(band_pos.data(), rstart_pad, sizeof(u32) * ((size_t)nr + 1), hipMemcpyDeviceToHost, st));
+    LZX_HIP(hipStreamSynchronize(st));
+    ar.drop(runs.runid); ar.drop(runs.runstart); ar.drop(runs.pstart); ar.drop(pos); ar.drop(rstart); ar.drop(rstart_pad);
+    // scatter order: quads sorted (stably) by column band
+    u32 *qkey = nullptr, *qkey_s = nullptr, *qidx = nullptr, *qsorted = nullptr, *bstart = nullptr;
+    LZX_TRY(ar.get(&qkey, nquads)); LZX_TRY(ar.get(&qkey_s, nquads)); LZX_TRY(ar.get(&qidx, nquads)); LZX_TRY(ar.get(&qsorted, nquads));
+    hipLaunchKernelGGL(k_pb_iota_widen, GRID(nquads), qcband, nquads, qkey, qidx);
+    LZX_TRY(pb_sort_pairs16(st, qkey, qkey_s, qidx, qsorted, nquads));
+    ar.drop(qkey); ar.drop(qidx); ar.drop(qcband);
+    {
+        uint2 *q_lcol = nullptr;
+        LZX_TRY(pb_alloc(&q_lcol, nquads + 1));
+        c->d_pb_lcol = reinterpret_cast<uint16_t *>(q_lcol);
+    }
+    LZX_TRY(pb_alloc(&c->d_pb_dst, nquads + 1));
+    hipLaunchKernelGGL(k_pb_quads, GRID(nquads), qsorted, plcol, nquads, reinterpret_cast<uint2 *>(c->d_pb_lcol), c->d_pb_dst);
+    LZX_TRY(ar.get(&bstart, (u64)nb + 1));
+    hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), qkey_s, nquads, nb, bstart);
+    LZX_TRY(pb_units(c, st, bstart, nb, LZX_PB_UNIT / 4, &c->d_pb_unit, &c->pb_units, &c->pb_units0));
+    *total_pad_out = total_pad;
+    LZX_HIP(hipStreamSynchronize(st));
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, const u32 *d_deg_local,
+                    const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total)
 {
     hipStream_t st = c->stream;
     if (total >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu entries do not fit 32-bit slots", (unsigned long long)total);
     const u32 nb = (u32)((c->xlen + LZX_PB_CB - 1) / LZX_PB_CB);
     if (nb >= (1u << 16)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u column bands (limit 65535)", nb);
-
-    // ---- row bands: consecutive local rows, closed at ~target entries or LZX_PB_RB rows; a row heavier than the
-    //      target is a band of its own.  Every wavefront of the gather pass gets one band (or one item of a very
-    //      heavy row), so work per wavefront is even although degrees are not.
     const u32 target = c->pb_target_opt > 0 ? (u32)c->pb_target_opt : LZX_PB_TARGET;
+
+    // ---- row bands: consecutive local rows (they are in descending degree order).
+    //  reduced bands first: as many rows as the wave-private y tile can give enough replica slots (a row with many
+    //      entries per column band sends many pieces in a row to the same slot), for as long as the band's runs stay
+    //      long enough to be cut into whole steps;
+    //  plain bands after them: closed at ~target entries or LZX_PB_RB rows.
     std::vector<u32> row0;
     row0.push_back(0);
+    u32 nred = 0;
+    u64 red_entries = 0;
+    u32 l = 0;
+    if (c->pb_reduce_opt != 0) {
+        const u64 min_run = c->pb_reduce_opt > 1 ? (u64)c->pb_reduce_opt : LZX_PBR_MIN_RUN;
+        while (l < c->n_loc_real) {
+            u32 rep = 1;
+            while (rep < 64 && (u64)rep * 2 * nb < h_nh[l]) rep <<= 1;
+            const u32 rows_max = LZX_PB_RB / rep;
+            u64 e = 0;
+            u32 r = 0;
+            while (r < rows_max && l + r < c->n_loc_real) e += h_nh[l + r++];
+            if (e < min_run * nb) break;
+            l += r;
+            row0.push_back(l);
+            red_entries += e;
+            ++nred;
+        }
+    }
     {
         u32 rows = 0;
         u64 cnt = 0;
-        for (u32 l = 0; l < c->n_loc_real; ++l) {
+        for (; l < c->n_loc_real; ++l) {
             const u32 nh = h_nh[l];
             if (rows > 0 && (cnt + nh > target || rows == LZX_PB_RB)) {
                 row0.push_back(l);
@@ -435,95 +841,69 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
             ++rows;
             cnt += nh;
         }
-        row0.push_back(c->n_loc_real);
+        if (rows > 0 || row0.size() == 1) row0.push_back(c->n_loc_real);
     }
     const u32 nr = (u32)row0.size() - 1;
     if (nr >= (1u << 24)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u row bands (limit 2^24)", nr);
+    LZX_TRY(pb_alloc(&c->d_pb_row0, (u64)nr + 1));
+    LZX_HIP(hipMemcpyAsync(c->d_pb_row0, row0.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
 
+    Arena ar;
+    // 1. emit + sort by (row band, column band, row, column): the gather order; the reduced bands' entries come first
     u64 *d_keys = nullptr, *d_sorted = nullptr;
-    u32 *d_head = nullptr, *d_runid = nullptr, *d_runstart = nullptr, *d_padlen = nullptr, *d_pstart = nullptr;
-    u32 *d_pos = nullptr, *d_rstart = nullptr, *d_rstart_pad = nullptr, *d_step0 = nullptr;
-    u32 *d_qkey = nullptr, *d_qkey_s = nullptr, *d_qidx = nullptr, *d_qsorted = nullptr, *d_bstart = nullptr;
-    uint16_t *d_prow = nullptr, *d_plcol = nullptr, *d_qcband = nullptr;
-    uint8_t *d_occ = nullptr;
-    void *d_tmp = nullptr;
-    int rc = LZX_OK;
-    auto free_tmp = [&]() { if (d_tmp) (void)hipFree(d_tmp); d_tmp = nullptr; };
-    auto cleanup = [&]() {
-        pb_free(d_keys); pb_free(d_sorted); pb_free(d_head); pb_free(d_runid); pb_free(d_runstart); pb_free(d_padlen);
-        pb_free(d_pstart); pb_free(d_pos); pb_free(d_rstart); pb_free(d_rstart_pad); pb_free(d_step0); pb_free(d_qkey);
-        pb_free(d_qkey_s); pb_free(d_qidx); pb_free(d_qsorted); pb_free(d_bstart); pb_free(d_prow); pb_free(d_plcol);
-        pb_free(d_qcband); pb_free(d_occ);
-        free_tmp();
-    };
-#define PB(call) do { rc = (call); if (rc != LZX_OK) { cleanup(); lzx_pb_release(c); return rc; } } while (0)
-#define PB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-        lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); lzx_pb_release(c); \
-        return e_ == hipErrorOutOfMemory ? LZX_ERR_NOMEM : LZX_ERR_HIP; } } while (0)
-#define GRID(n) dim3((u32)(((u64)(n) + 255) / 256)), dim3(256), 0, st
-
-    PB(pb_alloc(&c->d_pb_row0, (u64)nr + 1));
-    PB_HIP(hipMemcpyAsync(c->d_pb_row0, row0.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
-
-    // 1. emit + sort by (row band, column band, row, column): the (unpadded) GATHER order
-    PB(pb_alloc(&d_keys, total)); PB(pb_alloc(&d_sorted, total));
+    LZX_TRY(ar.get(&d_keys, total)); LZX_TRY(ar.get(&d_sorted, total));
     if (c->n_loc_real)
         hipLaunchKernelGGL(k_pb_emit, dim3(c->n_loc_real), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
                            d_old_of_local, d_deg_local, d_nh_off, c->hub_real, c->d_pb_row0, nr, d_keys);
-    size_t tb = 0;
-    PB_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_keys, d_sorted, (u64)total, 0, 64, st));
-    PB_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
-    PB_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_keys, d_sorted, (u64)total, 0, 64, st));
-    PB_HIP(hipStreamSynchronize(st));
-    free_tmp();
-    pb_free(d_keys);
+    LZX_TRY(pb_sort_keys(st, d_keys, d_sorted, total));
+    ar.drop(d_keys);
 
-    // 2. runs = maximal stretches of one (row band, column band); padded to whole quads
-    PB(pb_alloc(&d_head, total)); PB(pb_alloc(&d_runid, total));
-    hipLaunchKernelGGL(k_pb_heads, GRID(total), d_sorted, total, d_head);
-    tb = 0;
-    PB_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tb, d_head, d_runid, (u64)total, st));
-    PB_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
-    PB_HIP(hipcub::DeviceScan::InclusiveSum(d_tmp, tb, d_head, d_runid, (u64)total, st));
-    u32 nruns = 0;
-    PB_HIP(hipMemcpyAsync(&nruns, d_runid + (total - 1), sizeof(u32), hipMemcpyDeviceToHost, st));
-    PB_HIP(hipStreamSynchronize(st));
-    free_tmp();
-    PB(pb_alloc(&d_runstart, (u64)nruns + 1)); PB(pb_alloc(&d_padlen, (u64)nruns + 1)); PB(pb_alloc(&d_pstart, (u64)nruns + 1));
-    hipLaunchKernelGGL(k_pb_runstarts, GRID(total), d_head, d_runid, total, d_runstart);
-    PB_HIP(hipMemsetAsync(d_padlen + nruns, 0, sizeof(u32), st));
-    const u32 run_align = (c->pb_align_opt == 8 || c->pb_align_opt == 16 || c->pb_align_opt == 4) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
-    hipLaunchKernelGGL(k_pb_padlen, GRID(nruns), d_runstart, nruns, total, run_align, d_padlen);
-    tb = 0;
-    PB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_padlen, d_pstart, (u64)nruns + 1, st));
-    PB_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
-    PB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_padlen, d_pstart, (u64)nruns + 1, st));
-    u32 total_pad = 0;
-    PB_HIP(hipMemcpyAsync(&total_pad, d_pstart + nruns, sizeof(u32), hipMemcpyDeviceToHost, st));
-    PB_HIP(hipStreamSynchronize(st));
-    free_tmp();
-    pb_free(d_head); pb_free(d_padlen);
-    if (total_pad >= (1u << 31) || total_pad < total) { cleanup(); lzx_pb_release(c); LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: padded entry count overflows"); }
-    const u64 nquads = total_pad / 4;
-
-    // 3. padded positions: row / column in band per position (0xffff / column "CB" = the zero behind the staged
-    //    band for padding), column band per quad
-    PB(pb_alloc(&d_prow, (u64)total_pad + 8)); PB(pb_alloc(&d_plcol, (u64)total_pad + 8)); PB(pb_alloc(&d_qcband, nquads + 2));
-    PB(pb_alloc(&d_pos, total));
-    hipLaunchKernelGGL(k_pb_fill16, GRID(total_pad), d_prow, total_pad, (uint16_t)0xffffu);
-    hipLaunchKernelGGL(k_pb_fill16, GRID(total_pad), d_plcol, total_pad, (uint16_t)LZX_PB_CB);
-    hipLaunchKernelGGL(k_pb_fill16, GRID(nquads + 2), d_qcband, nquads + 2, (uint16_t)0xffffu);   // all-padding quads: no band
-    hipLaunchKernelGGL(k_pb_place, GRID(total), d_sorted, d_runid, d_runstart, d_pstart, total, d_prow, d_plcol, d_qcband, d_pos);
-    PB(pb_alloc(&d_rstart, (u64)nr + 1)); PB(pb_alloc(&d_rstart_pad, (u64)nr + 1));
-    hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), d_sorted, total, 40u, nr, d_rstart);
-    hipLaunchKernelGGL(k_pb_rstart_pad, GRID(nr + 1), d_rstart, d_pos, nr, total, total_pad, d_rstart_pad);
+    // 2. value positions.  [0, red_len): pieces of the reduced bands; [red_len, red_len + plain_pad): padded entries
+    //    of the plain bands.  prow = row in band per position (0xffff: padding).
+    const u64 plain_entries = total - red_entries;
+    uint16_t *d_prow = nullptr;
+    std::vector<u32> red_pos, plain_pos;
+    u32 pieces = 0, plain_pad = 0;
+    // the sizes of both parts are only known once their runs are laid out: build each into its own array first
+    uint16_t *d_prow_plain = nullptr, *d_prow_red = nullptr;
+    if (red_entries) {
+        LZX_TRY(ar.get(&d_prow_red, red_entries + 16));
+        hipLaunchKernelGGL(k_pb_fill16, GRID(red_entries + 16), d_prow_red, red_entries + 16, (uint16_t)0xffffu);
+        LZX_TRY(pb_build_reduced(c, st, d_sorted, red_entries, nred, nr, nb, d_prow_red, red_pos, &pieces));
+    }
+    const u32 red_len = (pieces + 7u) & ~7u;
+    if (plain_entries) {
+        // upper bound of the padded size: every run gains < 16 entries and there are at most min(entries, nr * nb) runs
+        const u64 max_runs = std::min<u64>(plain_entries, (u64)nr * nb);
+        const u64 bound = plain_entries + max_runs * 15 + 16;
+        if (bound >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: padded entry bound overflows");
+        LZX_TRY(ar.get(&d_prow_plain, bound));
+        hipLaunchKernelGGL(k_pb_fill16, GRID(bound), d_prow_plain, bound, (uint16_t)0xffffu);
+        LZX_TRY(pb_build_plain(c, st, d_sorted + red_entries, plain_entries, nr, nb, d_prow_plain, plain_pos, &plain_pad));
+    }
+    ar.drop(d_sorted);
+    const u64 len = (u64)red_len + plain_pad;
+    if (len >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu values do not fit 32-bit slots", (unsigned long long)len);
+    LZX_TRY(ar.get(&d_prow, len + 8));
+    hipLaunchKernelGGL(k_pb_fill16, GRID(len + 8), d_prow, len + 8, (uint16_t)0xffffu);
+    if (pieces) LZX_HIP(hipMemcpyAsync(d_prow, d_prow_red, sizeof(uint16_t) * pieces, hipMemcpyDeviceToDevice, st));
+    if (plain_pad) LZX_HIP(hipMemcpyAsync(d_prow + red_len, d_prow_plain, sizeof(uint16_t) * plain_pad, hipMemcpyDeviceToDevice, st));
+    LZX_HIP(hipStreamSynchronize(st));
+    ar.drop(d_prow_red); ar.drop(d_prow_plain);
+    // first position of every band
     std::vector<u32> rstart((size_t)nr + 1);
-    PB_HIP(hipMemcpyAsync(rstart.data(), d_rstart_pad, sizeof(u32) * ((size_t)nr + 1), hipMemcpyDeviceToHost, st));
-    PB_HIP(hipStreamSynchronize(st));
-    pb_free(d_sorted); pb_free(d_runid); pb_free(d_runstart); pb_free(d_pstart); pb_free(d_pos); pb_free(d_rstart);
+    for (u32 R = 0; R <= nr; ++R) {
+        if (R < nred) rstart[R] = red_pos[R];
+        else rstart[R] = red_len + (plain_entries ? plain_pos[R] : 0u);
+    }
+    rstart[nr] = (u32)len;
 
-    // 4. conflict-free LDS slots for the gather pass
-    PB(pb_alloc(&c->d_pb_lrow, (u64)total_pad + 8)); PB(pb_alloc(&c->d_pb_rep, (u64)nr));
+    // 3. conflict-free LDS slots for the gather pass
+    u32 *d_rstart_pad = nullptr, *d_step0 = nullptr;
+    uint8_t *d_occ = nullptr;
+    LZX_TRY(ar.get(&d_rstart_pad, (u64)nr + 1));
+    LZX_HIP(hipMemcpyAsync(d_rstart_pad, rstart.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
+    LZX_TRY(pb_alloc(&c->d_pb_lrow, len + 8)); LZX_TRY(pb_alloc(&c->d_pb_rep, (u64)nr));
     {
         std::vector<u32> step0((size_t)nr + 1), rep((size_t)nr, 1u);
         u64 steps = 0;
@@ -532,138 +912,113 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
             steps += (rstart[R + 1] - rstart[R] + 63u) / 64u;
         }
         step0[nr] = (u32)steps;
-        PB(pb_alloc(&d_step0, (u64)nr + 1)); PB(pb_alloc(&d_occ, (u64)total_pad + 8));
-        PB_HIP(hipMemcpyAsync(d_step0, step0.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
-        PB_HIP(hipMemcpyAsync(c->d_pb_rep, rep.data(), sizeof(u32) * nr, hipMemcpyHostToDevice, st));
-        PB_HIP(hipMemsetAsync(d_occ, 0, (u64)total_pad + 8, st));
+        LZX_TRY(ar.get(&d_step0, (u64)nr + 1)); LZX_TRY(ar.get(&d_occ, len + 8));
+        LZX_HIP(hipMemcpyAsync(d_step0, step0.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
+        LZX_HIP(hipMemcpyAsync(c->d_pb_rep, rep.data(), sizeof(u32) * nr, hipMemcpyHostToDevice, st));
+        LZX_HIP(hipMemsetAsync(d_occ, 0, len + 8, st));
         if (steps)
             hipLaunchKernelGGL(k_pb_occurrence, dim3((u32)steps), dim3(64), 0, st, d_prow, d_rstart_pad, d_step0, nr, d_occ,
                                c->d_pb_rep);
-        PB_HIP(hipMemcpyAsync(rep.data(), c->d_pb_rep, sizeof(u32) * nr, hipMemcpyDeviceToHost, st));
-        PB_HIP(hipStreamSynchronize(st));
+        LZX_HIP(hipMemcpyAsync(rep.data(), c->d_pb_rep, sizeof(u32) * nr, hipMemcpyDeviceToHost, st));
+        LZX_HIP(hipStreamSynchronize(st));
         // replicas per row: enough for the worst step of the band, but the tile holds LZX_PB_RB slots
         for (u32 R = 0; R < nr; ++R) {
             const u32 rows = row0[R + 1] - row0[R];
             const u32 room = std::max(1u, LZX_PB_RB / std::max(rows, 1u));
             rep[R] = std::max(1u, std::min(std::min(rep[R], room), 64u));
         }
-        PB_HIP(hipMemcpyAsync(c->d_pb_rep, rep.data(), sizeof(u32) * nr, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_pb_slots, GRID(total_pad), d_prow, d_occ, d_rstart_pad, c->d_pb_rep, nr, total_pad, c->d_pb_lrow);
-        PB_HIP(hipStreamSynchronize(st));
-        pb_free(d_step0); pb_free(d_occ); pb_free(d_prow); pb_free(d_rstart_pad);
+        LZX_HIP(hipMemcpyAsync(c->d_pb_rep, rep.data(), sizeof(u32) * nr, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_pb_slots, GRID(len), d_prow, d_occ, d_rstart_pad, c->d_pb_rep, nr, len, c->d_pb_lrow);
+        LZX_HIP(hipStreamSynchronize(st));
     }
 
-    // 5. scatter order: quads sorted (stably) by column band
-    PB(pb_alloc(&d_qkey, nquads)); PB(pb_alloc(&d_qkey_s, nquads)); PB(pb_alloc(&d_qidx, nquads)); PB(pb_alloc(&d_qsorted, nquads));
-    hipLaunchKernelGGL(k_pb_iota_widen, GRID(nquads), d_qcband, nquads, d_qkey, d_qidx);
-    tb = 0;
-    PB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_qkey, d_qkey_s, d_qidx, d_qsorted, (u64)nquads, 0, 16, st));
-    PB_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
-    PB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_qkey, d_qkey_s, d_qidx, d_qsorted, (u64)nquads, 0, 16, st));
-    PB_HIP(hipStreamSynchronize(st));
-    free_tmp();
-    pb_free(d_qkey); pb_free(d_qidx); pb_free(d_qcband);
-    {
-        uint2 *q_lcol = nullptr;
-        PB(pb_alloc(&q_lcol, nquads + 1));
-        c->d_pb_lcol = reinterpret_cast<uint16_t *>(q_lcol);
-    }
-    PB(pb_alloc(&c->d_pb_dst, nquads + 1));
-    hipLaunchKernelGGL(k_pb_quads, GRID(nquads), d_qsorted, d_plcol, nquads, reinterpret_cast<uint2 *>(c->d_pb_lcol), c->d_pb_dst);
-    PB(pb_alloc(&d_bstart, (u64)nb + 1));
-    hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), d_qkey_s, nquads, nb, d_bstart);
-    std::vector<u32> bstart((size_t)nb + 1);
-    PB_HIP(hipMemcpyAsync(bstart.data(), d_bstart, sizeof(u32) * ((size_t)nb + 1), hipMemcpyDeviceToHost, st));
-    PB_HIP(hipStreamSynchronize(st));
-    pb_free(d_qkey_s); pb_free(d_qsorted); pb_free(d_plcol); pb_free(d_bstart);
-
-    // scatter work units: (column band, first quad, last quad), at most LZX_PB_UNIT entries each
-    std::vector<u32> units;
-    const u32 unit_quads = LZX_PB_UNIT / 4;
-    for (u32 b = 0; b < nb; ++b)
-        for (u32 s = bstart[b]; s < bstart[b + 1]; s += unit_quads) {
-            units.push_back(b);
-            units.push_back(s);
-            units.push_back(std::min(bstart[b + 1], s + unit_quads));
-        }
-    c->pb_units = (u32)(units.size() / 3);
-    // units are sorted by column band: those whose band ends inside chunk 0 of the exchange layout come first
-    c->pb_units0 = c->pb_units;
-    if (c->overlap) {
-        const u64 chunk0_end = (u64)c->world * c->xs0;
-        u32 u0 = 0;
-        while (u0 < c->pb_units && ((u64)units[3 * u0] + 1) * LZX_PB_CB <= chunk0_end) ++u0;
-        c->pb_units0 = u0;
-    }
-    PB(pb_alloc(&c->d_pb_unit, units.size()));
-    if (!units.empty())
-        PB_HIP(hipMemcpyAsync(c->d_pb_unit, units.data(), sizeof(u32) * units.size(), hipMemcpyHostToDevice, st));
-
-    // 6. gather items (padded positions): one per band; a single-row band above 2 targets is cut into target-sized items
+    // 4. gather items: one per band; a band above 2 targets of values is cut into about target-sized items whose
+    //    per-row totals k_pb_finish adds in item order
     std::vector<u32> items, multi;
-    u32 slots = 0;
+    u64 slots = 0;
     for (u32 R = 0; R < nr; ++R) {
         const u32 beg = rstart[R], end = rstart[R + 1];
         if (beg == end) continue;
         const u32 rows = row0[R + 1] - row0[R];
-        if (rows == 1 && end - beg > 2 * target) {
-            multi.push_back(row0[R]);
-            multi.push_back(slots);
-            u32 cnt = 0;
-            for (u32 s = beg; s < end; s += target, ++cnt) {
-                items.push_back(R); items.push_back(s); items.push_back(std::min(end, s + target));
-                items.push_back(slots + cnt);
+        if (end - beg > 2 * target) {
+            const u32 cnt = (end - beg + target - 1) / target;
+            const u32 piece = ((end - beg + cnt - 1) / cnt + 63u) & ~63u;
+            u32 made = 0;
+            for (u32 s = beg; s < end; s += piece, ++made) {
+                items.push_back(R); items.push_back(s); items.push_back(std::min(end, s + piece));
+                items.push_back((u32)(slots + (u64)made * rows));
             }
-            multi.push_back(cnt);
-            slots += cnt;
+            for (u32 j = 0; j < rows; ++j) {
+                multi.push_back(row0[R] + j); multi.push_back((u32)(slots + j)); multi.push_back(made); multi.push_back(rows);
+            }
+            slots += (u64)made * rows;
+            if (slots >= 0xffffffffull) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: item totals overflow 32-bit slots");
         } else {
             items.push_back(R); items.push_back(beg); items.push_back(end); items.push_back(0xffffffffu);
         }
     }
     c->pb_n_items = (u32)(items.size() / 4);
-    c->pb_n_multi = (u32)(multi.size() / 3);
-    PB(pb_alloc(&c->d_pb_items, items.size())); PB(pb_alloc(&c->d_pb_multi, multi.size())); PB(pb_alloc(&c->d_pb_part, slots));
+    c->pb_n_multi = (u32)(multi.size() / 4);
+    LZX_TRY(pb_alloc(&c->d_pb_items, items.size())); LZX_TRY(pb_alloc(&c->d_pb_multi, multi.size())); LZX_TRY(pb_alloc(&c->d_pb_part, slots));
     if (!items.empty())
-        PB_HIP(hipMemcpyAsync(c->d_pb_items, items.data(), sizeof(u32) * items.size(), hipMemcpyHostToDevice, st));
+        LZX_HIP(hipMemcpyAsync(c->d_pb_items, items.data(), sizeof(u32) * items.size(), hipMemcpyHostToDevice, st));
     if (!multi.empty())
-        PB_HIP(hipMemcpyAsync(c->d_pb_multi, multi.data(), sizeof(u32) * multi.size(), hipMemcpyHostToDevice, st));
+        LZX_HIP(hipMemcpyAsync(c->d_pb_multi, multi.data(), sizeof(u32) * multi.size(), hipMemcpyHostToDevice, st));
 
-    PB(pb_alloc(&c->d_pb_val, (u64)total_pad + 8));
-    PB_HIP(hipMemsetAsync(c->d_pb_val, 0, sizeof(double) * ((u64)total_pad + 8), st));
-    PB_HIP(hipStreamSynchronize(st));
-    PB_HIP(hipGetLastError());
+    LZX_TRY(pb_alloc(&c->d_pb_val, len + 8));
+    LZX_HIP(hipMemsetAsync(c->d_pb_val, 0, sizeof(double) * (len + 8), st));
+    LZX_HIP(hipStreamSynchronize(st));
+    LZX_HIP(hipGetLastError());
 
     c->pb = true;
     c->pb_entries = total;
+    c->pbr_entries = red_entries;
+    c->pb_values = len;
+    c->pb_val_offset = red_len;
     c->pb_nr = nr;
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2, std::max(1u, (c->pb_n_items + waves_per_wg - 1) / waves_per_wg));
     c->pb_finish_grid = (c->pb_n_multi + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
-    cleanup();
-#undef PB
-#undef PB_HIP
-#undef GRID
     return LZX_OK;
+}
+#undef GRID
+}  // namespace
+
+int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, const u32 *d_deg_local,
+                   const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total)
+{
+    const int rc = pb_prepare_impl(c, d_code, d_old_of_local, d_deg_local, d_nh_off, h_nh, total);
+    if (rc != LZX_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        lzx_pb_release(c);
+    }
+    return rc;
 }
 
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready)
 {
     if (!c->pb) return LZX_OK;
-    if (c->pb_units) {
-        const size_t lds1 = ((size_t)LZX_PB_CB + 2) * sizeof(double);
-        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_scatter),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
-        const u32 first = chunk1_ready ? c->pb_units0 : c->pb_units;
-        if (first)
-            hipLaunchKernelGGL(k_pb_scatter, dim3(first), dim3(1024), lds1, c->stream, c->d_pb_unit,
-                               reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val);
-        if (chunk1_ready) {
-            LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
-            if (c->pb_units > first)
-                hipLaunchKernelGGL(k_pb_scatter, dim3(c->pb_units - first), dim3(1024), lds1, c->stream, c->d_pb_unit + 3 * (size_t)first,
-                                   reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val);
-        }
+    const size_t lds1 = ((size_t)LZX_PB_CB + 2) * sizeof(double);
+    if (c->pb_units)
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    if (c->pbr_units)
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pbr_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    double *val_plain = c->d_pb_val + c->pb_val_offset;
+    // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
+    auto scatter = [&](u32 r0, u32 r1, u32 p0, u32 p1) {
+        if (r1 > r0)
+            hipLaunchKernelGGL(k_pbr_scatter, dim3(r1 - r0), dim3(1024), lds1, c->stream, c->d_pbr_unit + 3 * (size_t)r0,
+                               c->d_pbr_code, c->d_pbr_base, x, c->xlen, c->d_pb_val);
+        if (p1 > p0)
+            hipLaunchKernelGGL(k_pb_scatter, dim3(p1 - p0), dim3(1024), lds1, c->stream, c->d_pb_unit + 3 * (size_t)p0,
+                               reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, val_plain);
+    };
+    if (chunk1_ready) {
+        scatter(0, c->pbr_units0, 0, c->pb_units0);
+        LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
+        scatter(c->pbr_units0, c->pbr_units, c->pb_units0, c->pb_units);
+    } else {
+        scatter(0, c->pbr_units, 0, c->pb_units);
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);
@@ -673,8 +1028,9 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_lrow,
                        c->d_pb_val, v, q_loc, c->d_pb_part, partials);
     if (c->pb_finish_grid)
-        hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_pb_multi,
-                           c->pb_n_multi, c->d_pb_part, v, q_loc, partials + c->pb_gather_grid);
+        hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
+                           reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, v, q_loc,
+                           partials + c->pb_gather_grid);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }

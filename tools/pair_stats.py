@@ -24,3 +24,17 @@ for lo, hi in ((0, 128), (128, 1024), (1024, 8192), (8192, 10**9)):
     m = (d_of >= lo) & (d_of < hi)
     uu = np.unique(pairs[m])
     print(f"  rows with degree in [{lo},{hi}): entries {int(m.sum())} pairs {len(uu)} ratio {len(uu) / max(1, int(m.sum())):.3f}")
+# histogram of entries per pair, and the padding of a sliced-ELL over the pairs of each band taken in row (degree-rank) order
+pk, cnt = np.unique(rank[rows[keep]] + band * (1 << 24), return_counts=True)   # sorted by (band, row rank)
+for lo, hi in ((1, 2), (2, 3), (3, 5), (5, 9), (9, 17), (17, 33), (33, 65), (65, 257), (257, 10**9)):
+    m = (cnt >= lo) & (cnt < hi)
+    print(f"  pairs with {lo}..{hi - 1} entries: {int(m.sum())} pairs ({m.sum() / len(cnt):.3f}), entries {int(cnt[m].sum())} ({cnt[m].sum() / total:.3f})")
+for S in (16, 32, 64):
+    pad = (-len(cnt)) % S
+    c2 = np.concatenate([cnt, np.zeros(pad, dtype=cnt.dtype)]).reshape(-1, S)
+    w = c2.max(axis=1)
+    w4 = (w + 3) // 4 * 4
+    print(f"  slices of {S} pairs in (band, row) order: padded entries {int(w.sum()) * S} ({w.sum() * S / total:.2f}x), widths rounded to 4: {w4.sum() * S / total:.2f}x")
+    capped = np.minimum(c2, 32)
+    wc = capped.max(axis=1)
+    print(f"     with pairs cut at 32 entries: {wc.sum() * S / total:.2f}x (+ {int(np.maximum(cnt - 32, 0).sum())} entries in overflow items)")

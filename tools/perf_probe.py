@@ -24,7 +24,7 @@ def run(name, opts_list, k=20):
         bytes_ = 4 * gi["nnz"] + 4 * (n + 1) + 8 * n + 8 * n
         a, b, _, xn, st = eng.lanczos(np.ones(n), k, want_q=False)
         print(f"{name} {opts} gen={tg:.1f}s n={n} nnz={gi['nnz']} maxdeg={gi['max_degree']} long={gi['long_rows']} "
-              f"padded={gi['sell_padded']} hub={gi['hub_entries']} pb={gi['pb_entries']} | spmv avg {avg:.4f} ms min {mn:.4f} ms -> "
+              f"padded={gi['sell_padded']} hub={gi['hub_entries']} pb={gi['pb_entries']} reduced={gi['pb_reduced_entries']} values={gi['pb_values']} | spmv avg {avg:.4f} ms min {mn:.4f} ms -> "
               f"{bytes_ / mn / 1e6:.1f} GB/s ({bytes_ / mn / 1e6 / 8000 * 100:.1f}% of 8 TB/s) | "
               f"lanczos k={k}: loop {st['loop_ms']:.2f} ms, spmv {st['spmv_ms']:.2f}, vec {st['vec_ms']:.2f} -> "
               f"{k / st['loop_ms'] * 1e3:.1f} it/s", flush=True)
@@ -47,7 +47,7 @@ if __name__ == "__main__":
         opts = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=8192),
                 dict(propagation_blocking=1, hub_entries=19000)]
     if "hubk" in sets:
-        opts = [dict(), dict(propagation_blocking=0), dict(phase_mask=1), dict(phase_mask=2)]
+        opts = [dict(), dict(pb_reduce=0), dict(pb_reduce=256), dict(pb_reduce=768)]
     if "phase" in sets:
         opts = [dict(phase_mask=1), dict(phase_mask=2), dict(phase_mask=1, hub_entries=0), dict(phase_mask=2, hub_entries=0),
                 dict(long_row=256), dict(long_row=4096), dict(long_row=65536)]
