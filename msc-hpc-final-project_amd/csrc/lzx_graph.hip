@@ -172,14 +172,14 @@ k_row_hub_count(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, 
 // code < hub; pad with `pad_code` (an LDS slot that holds 0).
 __global__ void k_fill_sell_hub(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old,
                                 const u32 *old_of_local, const u32 *deg_local, u32 n_loc_real, u32 row0,
-                                u32 n_loc_pad, const u64 *slice_off, const u32 *slice_w, u32 *cols, u32 hub,
+                                u32 n_loc_pad, const u64 *slice_off, const u32 *slice_w, uint16_t *cols, u32 hub,
                                 u32 pad_code)
 {
     const u32 l = row0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= n_loc_pad) return;
     const u32 s = (l - row0) >> 6, lane = (l - row0) & 63;
     const u32 w = slice_w[s];
-    u32 *out = cols + slice_off[s] + (size_t)lane * 4;   // packet p of this lane: out[p * 256 .. +4)
+    uint16_t *out = cols + slice_off[s] + (size_t)lane * 4;   // packet p of this lane: out[p * 256 .. +4), 16-bit codes
     u32 kept = 0;
     if (l < n_loc_real) {
         const u32 d = deg_local[l];
@@ -187,17 +187,17 @@ __global__ void k_fill_sell_hub(const u64 *row_ptr, const u32 *col_idx, const u3
         for (u32 k = 0; k < d; ++k) {
             const u32 cde = code_of_old[col_idx[base + k]];
             if (cde < hub) {
-                out[(size_t)(kept >> 2) * 256 + (kept & 3)] = cde;
+                out[(size_t)(kept >> 2) * 256 + (kept & 3)] = (uint16_t)cde;
                 ++kept;
             }
         }
     }
-    for (; kept < w; ++kept) out[(size_t)(kept >> 2) * 256 + (kept & 3)] = pad_code;
+    for (; kept < w; ++kept) out[(size_t)(kept >> 2) * 256 + (kept & 3)] = (uint16_t)pad_code;
 }
 
 __global__ void __launch_bounds__(64)
 k_fill_long_hub(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, const u32 *old_of_local,
-                const u32 *deg_local, u32 n_loc_real, const u64 *long_ptr, u32 *long_cols, u32 hub, u32 pad_code)
+                const u32 *deg_local, u32 n_loc_real, const u64 *long_ptr, uint16_t *long_cols, u32 hub, u32 pad_code)
 {
     const u32 r = blockIdx.x, lane = threadIdx.x;
     const u64 beg = long_ptr[r], end = long_ptr[r + 1];
@@ -214,11 +214,11 @@ k_fill_long_hub(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, 
                 keep = cde < hub;
             }
             const unsigned long long m = __ballot(keep);
-            if (keep) long_cols[out + __popcll(m & ((1ull << lane) - 1ull))] = cde;
+            if (keep) long_cols[out + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)cde;
             out += __popcll(m);
         }
     }
-    for (u64 k = out + lane; k < end; k += 64) long_cols[k] = pad_code;
+    for (u64 k = out + lane; k < end; k += 64) long_cols[k] = (uint16_t)pad_code;
 }
 
 static u32 round_up(u32 a, u32 m) { return (a + m - 1) / m * m; }
@@ -433,8 +433,10 @@ int lzx_graph_prepare(lzx_ctx *c)
     // ---- 4. upload tables, fill column codes ----
     PREP(dev_alloc(&c->d_slice_off, c->n_slices)); PREP(dev_alloc(&c->d_slice_w, c->n_slices));
     // + 1 KiB: the SpMV's pipelined loads read one (clamped) packet row past a zero-width last slice / short item
-    PREP(dev_alloc(&c->d_sell_cols, c->sell_elems + 1024));
-    PREP(dev_alloc(&c->d_long_cols, c->long_elems + 1024));
+    // (staged-only tables of the propagation-blocking mode hold 16-bit codes: half the bytes)
+    c->codes16 = pb;
+    PREP(dev_alloc(&c->d_sell_cols, pb ? (c->sell_elems + 1025) / 2 + 512 : c->sell_elems + 1024));
+    PREP(dev_alloc(&c->d_long_cols, pb ? (c->long_elems + 1025) / 2 + 512 : c->long_elems + 1024));
     PREP(dev_alloc(&c->d_item_beg, c->n_items)); PREP(dev_alloc(&c->d_item_len, c->n_items));
     PREP(dev_alloc(&c->d_item_first, (u64)c->n_long64 + 1));
     PREP(dev_alloc(&c->d_long_partial, c->n_items));
@@ -454,7 +456,7 @@ int lzx_graph_prepare(lzx_ctx *c)
         if (pb)
             hipLaunchKernelGGL(k_fill_sell_hub, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx,
                                d_code, d_old_of_local, d_deg_local, c->n_loc_real, c->n_long64, c->n_loc_pad,
-                               c->d_slice_off, c->d_slice_w, c->d_sell_cols, c->hub_real, sentinel);
+                               c->d_slice_off, c->d_slice_w, reinterpret_cast<uint16_t *>(c->d_sell_cols), c->hub_real, sentinel);
         else
             hipLaunchKernelGGL(k_fill_sell, dim3((rows + 255) / 256), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx,
                                d_code, d_old_of_local, d_deg_local, c->n_loc_real, c->n_long64, c->n_loc_pad,
@@ -463,8 +465,8 @@ int lzx_graph_prepare(lzx_ctx *c)
     if (c->n_long64) {
         if (pb)
             hipLaunchKernelGGL(k_fill_long_hub, dim3(c->n_long64), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
-                               d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, c->d_long_cols, c->hub_real,
-                               sentinel);
+                               d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, reinterpret_cast<uint16_t *>(c->d_long_cols),
+                               c->hub_real, sentinel);
         else
             hipLaunchKernelGGL(k_fill_long, dim3(c->n_long64), dim3(256), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
                                d_old_of_local, d_deg_local, c->n_loc_real, d_long_ptr, c->d_long_cols, sentinel);

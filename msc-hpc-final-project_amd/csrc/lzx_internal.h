@@ -124,6 +124,7 @@ struct lzx_ctx {
     u64 sell_elems = 0;
     u64 *d_slice_off = nullptr;        // [n_slices] element offset of slice s in d_sell_cols
     u32 *d_slice_w = nullptr;          // [n_slices] width (multiple of 4)
+    bool codes16 = false;              // staged-only tables (propagation-blocking mode): 16-bit codes
     u32 *d_sell_cols = nullptr;
 
     // split rows

@@ -95,9 +95,29 @@ __device__ __forceinline__ uint4 load_idx4(const uint4 *p)
     return *p;
 }
 
+// staged-only tables (HUB == 2) hold 16-bit codes: 8-byte packets of four
+template <bool NT>
+__device__ __forceinline__ uint4 load_idx4(const uint2 *p)
+{
+    uint2 r;
+    if (NT) {
+        r.x = __builtin_nontemporal_load(&p->x);
+        r.y = __builtin_nontemporal_load(&p->y);
+    } else {
+        r = *p;
+    }
+    return make_uint4(r.x & 0xffffu, r.x >> 16, r.y & 0xffffu, r.y >> 16);
+}
+template <int HUB> struct CodeTable { using packet = uint4; using code = u32; };
+template <> struct CodeTable<2> { using packet = uint2; using code = uint16_t; };
+
 template <int HUB, bool NT>
 __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
 {
+    using PK = typename CodeTable<HUB>::packet;
+    using CODE = typename CodeTable<HUB>::code;
+    const CODE *long_cols = reinterpret_cast<const CODE *>(a.long_cols);
+    const CODE *sell_cols = reinterpret_cast<const CODE *>(a.sell_cols);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *hubv = lds;
     double *wsum = lds + a.hub;  // 16 doubles behind the staged entries
@@ -141,13 +161,13 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
             const u64 d_beg = a.item_beg[di];
             const u32 d_pk = a.item_len[di] >> 2;
             auto issue = [&](u32 j, uint4 &k0, uint4 &k1) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + lane_u64(d_beg, j));
+                const PK *p = reinterpret_cast<const PK *>(long_cols + lane_u64(d_beg, j));
                 const u32 packets = lane_u32(d_pk, j);
                 k0 = load_idx4<NT>(p + (lane < packets ? lane : 0));
                 k1 = load_idx4<NT>(p + (lane + 64 < packets ? lane + 64 : 0));
             };
             auto consume = [&](u32 j, const uint4 &k0, const uint4 &k1) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(a.long_cols + lane_u64(d_beg, j));
+                const PK *p = reinterpret_cast<const PK *>(long_cols + lane_u64(d_beg, j));
                 const u32 packets = lane_u32(d_pk, j);
                 double acc = 0.0;
                 if (lane < packets) {
@@ -213,14 +233,14 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
             const u64 d_off = a.slice_off[di];
             const u32 d_st = a.slice_w[di] >> 2;   // packets per lane
             auto issue = [&](u32 j, uint4 (&f)[4], double &qrow) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + lane_u64(d_off, j)) + lane;
+                const PK *p = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, j)) + lane;
                 const u32 st = lane_u32(d_st, j);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) f[u] = load_idx4<NT>(p + (size_t)((u32)u < st ? u : 0) * 64);
                 qrow = a.q_loc[a.row0 + (w0 + (base + j) * waves) * 64 + lane];
             };
             auto consume = [&](u32 j, const uint4 (&f)[4], double qrow) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(a.sell_cols + lane_u64(d_off, j)) + lane;
+                const PK *p = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, j)) + lane;
                 const u32 st = lane_u32(d_st, j);
                 double acc = 0.0;
 #pragma unroll
@@ -449,7 +469,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.xs0 = c->xs0;
     const bool nt = c->nt_opt > 0;
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[0], c->stream));
-    if (c->hub > 0 && c->pb) {
+    if (c->codes16) {
         if (nt) LZX_TRY((launch_spmv_t<2, true>(c, a)));
         else    LZX_TRY((launch_spmv_t<2, false>(c, a)));
     } else if (c->hub > 0) {

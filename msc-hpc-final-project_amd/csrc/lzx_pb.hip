@@ -30,6 +30,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "lzx_internal.h"
 
@@ -308,7 +309,7 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 // unit 64 quads at a time (lane = consecutive quad): contiguous loads, and 32-byte-per-lane stores that are
 // contiguous inside a run.  4 quads per lane in flight.
 __global__ void __launch_bounds__(1024)
-k_pb_scatter(const u32 *unit, const uint2 *q_lcol, const u32 *q_dst, const double *__restrict__ x, u64 xlen, double *val)
+k_pb_scatter(const u32 *unit, const uint2 *q_lcol, const u32 *q_dst, const double *__restrict__ x, u64 xlen, double *val, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) double tile[];   // LZX_PB_CB staged values + a zero for padding
     const u32 band = unit[3 * blockIdx.x], beg = unit[3 * blockIdx.x + 1], end = unit[3 * blockIdx.x + 2];
@@ -334,13 +335,18 @@ k_pb_scatter(const u32 *unit, const uint2 *q_lcol, const u32 *q_dst, const doubl
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             double2 lo, hi;
+            if (ablate != 2) {
             lo.x = tile[c[u].x & 0xffffu];
             lo.y = tile[c[u].x >> 16];
             hi.x = tile[c[u].y & 0xffffu];
             hi.y = tile[c[u].y >> 16];
+            }
+            if (ablate == 2) { lo.x = c[u].x; lo.y = c[u].y; hi = lo; }
             double2 *out = reinterpret_cast<double2 *>(val + d[u]);   // 32-byte aligned: slots of a quad
+            if (ablate == 1) { if (lo.x + lo.y + hi.x + hi.y == 1.2345e-300) out[0] = lo; continue; }
+            if (ablate == 4) out = reinterpret_cast<double2 *>(val + (size_t)(j + u * 64) * 4);
             out[0] = lo;
-            out[1] = hi;
+            if (ablate != 3) out[1] = hi;
         }
     }
     for (; j < wend; j += 64) {
@@ -1011,7 +1017,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                                c->d_pbr_code, c->d_pbr_base, x, c->xlen, c->d_pb_val);
         if (p1 > p0)
             hipLaunchKernelGGL(k_pb_scatter, dim3(p1 - p0), dim3(1024), lds1, c->stream, c->d_pb_unit + 3 * (size_t)p0,
-                               reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, val_plain);
+                               reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, val_plain, getenv("LZX_ABLATE") ? atoi(getenv("LZX_ABLATE")) : 0);
     };
     if (chunk1_ready) {
         scatter(0, c->pbr_units0, 0, c->pb_units0);

@@ -48,6 +48,8 @@ if __name__ == "__main__":
                 dict(propagation_blocking=1, hub_entries=19000)]
     if "hubk" in sets:
         opts = [dict(), dict(pb_reduce=0), dict(pb_reduce=256), dict(pb_reduce=768)]
+    if "one" in sets:
+        opts = [dict(pb_reduce=0)]
     if "phase" in sets:
         opts = [dict(phase_mask=1), dict(phase_mask=2), dict(phase_mask=1, hub_entries=0), dict(phase_mask=2, hub_entries=0),
                 dict(long_row=256), dict(long_row=4096), dict(long_row=65536)]
