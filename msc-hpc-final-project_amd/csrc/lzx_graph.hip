@@ -241,17 +241,12 @@ int lzx_graph_prepare(lzx_ctx *c)
     c->n_loc_real = (rank < n) ? (u32)((n - rank + world - 1) / world) : 0;
     if (c->iolen + 65536 >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "exchange layout does not fit 32-bit codes");
 
-    // Propagation blocking (lzx_pb.hip) for every entry whose column is not staged in LDS: worth its two extra
-    // launches once x no longer sits in the L2s.  -1 = decide here.
-    // Measured: ahead of the plain gather once x no longer fits the caches (C3: 1.65 vs 2.14 ms),
-    // behind it while x does (C2, 8 MB: 0.24 vs 0.13 ms); its fixed costs (one x band per scatter workgroup, fewer row
-    // bands than wavefronts) eat the gain when a rank's share is small (tools/rank_probe.py, C3 per-rank SpMV, plain /
-    // blocked: P=2 1.10 / 0.95, P=4 0.59 / 0.55, P=8 0.305 / 0.327 ms).  -1 = decide here.
-    bool pb = c->pb_opt > 0 || (c->pb_opt < 0 && n >= (4u << 20) && c->nnz / (u64)world >= (64u << 20));
-    // ... but only the blocked SpMV can start on the first chunk of the exchange while the second is still on the
-    // wire (its scatter walks column bands in order), which is worth more than those fixed costs: with several ranks
-    // and the overlapped exchange allowed, block from 16 Mi entries per rank.
-    if (c->pb_opt < 0 && world > 1 && c->overlap_opt != 0 && n >= (4u << 20) && c->nnz / (u64)world >= (16u << 20)) pb = true;
+    // Propagation blocking (lzx_pb.hip) for every entry whose column is not staged in LDS.  -1 = decide here.
+    // Measured (DESIGN.md section 3, 1 GPU, plain / blocked SpMV): C3 (10 M vertices, x far beyond the L2s) 2.13 / 1.05 ms;
+    // C2 (1 M vertices, x = 8 MB, L2-resident) 0.136 / 0.103 ms -- since high-degree rows cross the two passes as partial
+    // sums the blocked form also wins while x still fits the caches.  Below about 8 Mi entries per rank its extra
+    // launches and the per-unit 128 KiB column band cost more than the gathers they replace.
+    bool pb = c->pb_opt > 0 || (c->pb_opt < 0 && n >= (512u << 10) && c->nnz / (u64)world >= (8u << 20));
     // hub entries staged in LDS by k_spmv: 8192 (64 KiB, two workgroups per CU) when k_spmv also gathers from
     // memory; 16384 (128 KiB, one per CU) in propagation-blocking mode, where it only ever reads LDS.
     u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : (pb ? 16384 : 8192);

@@ -691,7 +691,7 @@ int pb_units(const lzx_ctx *c, hipStream_t st, const u32 *d_bstart, u32 nb, u32 
 
 // Reduced bands [0, nred): keys[0, count) sorted.  Leaves the scatter tables in c, the row of every piece in
 // prow[0, *pieces) and the first value position of every reduced band (and the end) in band_pos[0 .. nred].
-int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nred, u32 nr, u32 nb, uint16_t *prow,
+int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nred, u32 nr, u32 nb, u32 unit_cap, uint16_t *prow,
                      std::vector<u32> &band_pos, u32 *pieces)
 {
     Arena ar;
@@ -743,7 +743,7 @@ int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32
                        c->d_pbr_code, c->d_pbr_base);
     LZX_TRY(ar.get(&bstart, (u64)nb + 1));
     hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), skey_s, nsteps, nb, bstart);
-    LZX_TRY(pb_units(c, st, bstart, nb, LZX_PB_UNIT / LZX_PBR_STEP, &c->d_pbr_unit, &c->pbr_units, &c->pbr_units0));
+    LZX_TRY(pb_units(c, st, bstart, nb, unit_cap / LZX_PBR_STEP, &c->d_pbr_unit, &c->pbr_units, &c->pbr_units0));
     c->pbr_steps = nsteps;
     LZX_HIP(hipStreamSynchronize(st));
     LZX_HIP(hipGetLastError());
@@ -753,7 +753,7 @@ int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32
 // Plain bands: keys[0, count) sorted (all of bands >= nred).  Leaves the quad scatter tables in c, the row of every
 // padded position in prow[0, *total_pad) and the first padded position of every band in band_pos[0 .. nr]
 // (relative to this part; bands < nred get 0).
-int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nr, u32 nb, uint16_t *prow,
+int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nr, u32 nb, u32 unit_cap, uint16_t *prow,
                    std::vector<u32> &band_pos, u32 *total_pad_out)
 {
     Arena ar;
@@ -792,7 +792,7 @@ int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 n
     hipLaunchKernelGGL(k_pb_quads, GRID(nquads), qsorted, plcol, nquads, reinterpret_cast<uint2 *>(c->d_pb_lcol), c->d_pb_dst);
     LZX_TRY(ar.get(&bstart, (u64)nb + 1));
     hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), qkey_s, nquads, nb, bstart);
-    LZX_TRY(pb_units(c, st, bstart, nb, LZX_PB_UNIT / 4, &c->d_pb_unit, &c->pb_units, &c->pb_units0));
+    LZX_TRY(pb_units(c, st, bstart, nb, unit_cap / 4, &c->d_pb_unit, &c->pb_units, &c->pb_units0));
     *total_pad_out = total_pad;
     LZX_HIP(hipStreamSynchronize(st));
     LZX_HIP(hipGetLastError());
@@ -806,7 +806,17 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     if (total >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu entries do not fit 32-bit slots", (unsigned long long)total);
     const u32 nb = (u32)((c->xlen + LZX_PB_CB - 1) / LZX_PB_CB);
     if (nb >= (1u << 16)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u column bands (limit 65535)", nb);
-    const u32 target = c->pb_target_opt > 0 ? (u32)c->pb_target_opt : LZX_PB_TARGET;
+    // values per gather item / entries per plain band: every wavefront slot of the gather pass (2 workgroups of 8 per
+    // CU) should get a few items, and an item should not be shorter than its fold is worth
+    u32 target = LZX_PB_TARGET;
+    {
+        const u64 want = total / ((u64)c->cu_count * 32);
+        target = (u32)std::min<u64>(LZX_PB_TARGET, std::max<u64>(4096, (want + 1023) & ~1023ull));
+    }
+    if (c->pb_target_opt > 0) target = (u32)c->pb_target_opt;
+    // entries per scatter unit: at least four units per CU (each restages its 128 KiB column band, which small graphs
+    // hold in L2), at most LZX_PB_UNIT
+    const u32 unit_cap = (u32)std::min<u64>(LZX_PB_UNIT, std::max<u64>(8192, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
 
     // ---- row bands: consecutive local rows (they are in descending degree order).
     //  reduced bands first: as many rows as the wave-private y tile can give enough replica slots (a row with many
@@ -875,7 +885,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     if (red_entries) {
         LZX_TRY(ar.get(&d_prow_red, red_entries + 16));
         hipLaunchKernelGGL(k_pb_fill16, GRID(red_entries + 16), d_prow_red, red_entries + 16, (uint16_t)0xffffu);
-        LZX_TRY(pb_build_reduced(c, st, d_sorted, red_entries, nred, nr, nb, d_prow_red, red_pos, &pieces));
+        LZX_TRY(pb_build_reduced(c, st, d_sorted, red_entries, nred, nr, nb, unit_cap, d_prow_red, red_pos, &pieces));
     }
     const u32 red_len = (pieces + 7u) & ~7u;
     if (plain_entries) {
@@ -885,7 +895,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         if (bound >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: padded entry bound overflows");
         LZX_TRY(ar.get(&d_prow_plain, bound));
         hipLaunchKernelGGL(k_pb_fill16, GRID(bound), d_prow_plain, bound, (uint16_t)0xffffu);
-        LZX_TRY(pb_build_plain(c, st, d_sorted + red_entries, plain_entries, nr, nb, d_prow_plain, plain_pos, &plain_pad));
+        LZX_TRY(pb_build_plain(c, st, d_sorted + red_entries, plain_entries, nr, nb, unit_cap, d_prow_plain, plain_pos, &plain_pad));
     }
     ar.drop(d_sorted);
     const u64 len = (u64)red_len + plain_pad;
