@@ -47,6 +47,9 @@ extern "C" int lzx_create(lzx_handle *out, int device_id)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_phase2, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c0, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming);
@@ -76,10 +79,13 @@ extern "C" void lzx_destroy(lzx_handle c)
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->ev_phase) (void)hipEventDestroy(c->ev_phase);
     if (c->ev_phase2) (void)hipEventDestroy(c->ev_phase2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_q) (void)hipEventDestroy(c->ev_q);
     if (c->ev_c0) (void)hipEventDestroy(c->ev_c0);
     if (c->ev_c1) (void)hipEventDestroy(c->ev_c1);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -97,6 +103,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_target")) c->pb_target_opt = value;
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "pb_reduce")) c->pb_reduce_opt = value;
+    else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;

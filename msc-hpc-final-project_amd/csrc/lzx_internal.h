@@ -69,6 +69,8 @@ struct lzx_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;                    // exchange stream (chunked all-gather overlapping the SpMV)
     hipEvent_t ev_q = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;   // q_{j+1} slice ready / chunk 0 / chunk 1 arrived
+    hipStream_t stream3 = nullptr;                    // side stream of the blocked SpMV (staged-columns kernel)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_phase2 = nullptr;                   // cross-handle ordering on stream2 (local communicator)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;       // scratch timing pair
     hipEvent_t ev_phase = nullptr;                    // cross-handle ordering in local-comm mode
@@ -113,6 +115,7 @@ struct lzx_ctx {
     u32 pb_units0 = 0;                 // scatter units whose column band lies wholly in chunk 0
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
+    int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
     int64_t pb_reduce_opt = -1;        // reduced bands: -1 auto (on), 0 off, > 1: minimum average run length
     int64_t long_row_opt = -1;         // split-row threshold override
     int64_t phase_mask_opt = 3;        // debug: 1 = split rows only, 2 = body only
@@ -195,7 +198,8 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
                    const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total);
 void lzx_pb_release(lzx_ctx *c);
 // chunk1_ready (may be null): event after which the second chunk of the exchange layout is valid in x
-int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready);
+int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
+                  hipEvent_t v_ready);
 u32 lzx_pb_partials(const lzx_ctx *c);
 
 // ---- lzx_kernels.hip ----

@@ -1011,7 +1011,8 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
     return rc;
 }
 
-int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready)
+int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
+                  hipEvent_t v_ready)
 {
     if (!c->pb) return LZX_OK;
     const size_t lds1 = ((size_t)LZX_PB_CB + 2) * sizeof(double);
@@ -1037,6 +1038,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         scatter(0, c->pbr_units, 0, c->pb_units);
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
+    if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);
     LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

@@ -50,6 +50,8 @@ if __name__ == "__main__":
         opts = [dict(), dict(pb_reduce=0), dict(pb_reduce=256), dict(pb_reduce=768)]
     if "c2pb" in sets:
         opts = [dict(), dict(propagation_blocking=1), dict(propagation_blocking=1, pb_reduce=128), dict(propagation_blocking=1, pb_reduce=64), dict(propagation_blocking=1, pb_target=2048), dict(propagation_blocking=1, hub_entries=8192)]
+    if "side" in sets:
+        opts = [dict(), dict(side_stream=0), dict(), dict(side_stream=0)]
     if "one" in sets:
         opts = [dict(pb_reduce=0)]
     if "phase" in sets:
