@@ -103,6 +103,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_target")) c->pb_target_opt = value;
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "pb_reduce")) c->pb_reduce_opt = value;
+    else if (!strcmp(name, "pb_unit")) c->pb_unit_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
@@ -368,7 +369,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         memset(stats, 0, sizeof *stats);
         stats->loop_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats->iters = k;
-        stats->spmv_kernels = 1 + (c0->fin_grid > 0 ? 1 : 0) + (c0->pb ? 2 + (c0->pbr_units ? 1 : 0) + (c0->pb_finish_grid ? 1 : 0) : 0);
+        stats->spmv_kernels = 1 + (c0->fin_grid > 0 ? 1 : 0) + (c0->pb ? 2 + (c0->pb_finish_grid ? 1 : 0) : 0);
         stats->spmv_bytes = spmv_algorithmic_bytes(c0);
         stats->spmv_ms_min = 1e300;
         for (size_t i = 1; i < mk.used; ++i) {

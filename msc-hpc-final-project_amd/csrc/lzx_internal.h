@@ -116,6 +116,7 @@ struct lzx_ctx {
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
     int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
+    int64_t pb_unit_opt = -1;          // entries per scatter unit override
     int64_t pb_reduce_opt = -1;        // reduced bands: -1 auto (on), 0 off, > 1: minimum average run length
     int64_t long_row_opt = -1;         // split-row threshold override
     int64_t phase_mask_opt = 3;        // debug: 1 = split rows only, 2 = body only
@@ -149,7 +150,7 @@ struct lzx_ctx {
     u32 *d_pb_dst = nullptr;           // [pb_entries] scatter order: slot in d_pb_val (gather order)
     uint16_t *d_pb_lrow = nullptr;     // [pb_entries] gather order: slot in the band's y tile (row * rep + replica)
     double *d_pb_val = nullptr;        // [pb_entries] gathered x values in gather order (scratch)
-    u32 *d_pb_unit = nullptr;          // [pb_units][3] band, begin, end (scatter order)
+    u32 *d_pb_unit = nullptr;          // [pb_units][5] band, first / last step (reduced part), first / last quad (plain part)
     u32 *d_pb_row0 = nullptr;          // [pb_nr + 1] first local row of each row band
     u32 *d_pb_rep = nullptr;           // [pb_nr] LDS slots per row in that band's y tile
     u32 *d_pb_items = nullptr;         // [pb_n_items][4] row band, begin, end (gather order), slot or ~0
@@ -162,8 +163,7 @@ struct lzx_ctx {
     u64 pb_val_offset = 0;             // first value of the plain bands in d_pb_val (the reduced bands' pieces come first)
     uint4 *d_pbr_code = nullptr;       // [pbr_steps][64] scatter order: 8 x (column in band | piece-end flag) per lane
     u32 *d_pbr_base = nullptr;         // [pbr_steps] first value slot of the step
-    u32 *d_pbr_unit = nullptr;         // [pbr_units][3] band, first step, last step
-    u32 pbr_steps = 0, pbr_units = 0, pbr_units0 = 0;
+    u32 pbr_steps = 0;
 
     // vectors and scalars
     double *d_v = nullptr;             // [ldq]

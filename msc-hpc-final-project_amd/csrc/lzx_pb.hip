@@ -17,7 +17,7 @@
 //       touches the tile, so additions happen in program order.  The tile is then folded (rep replicas per row),
 //       added to v, and the wave forms its share of alpha = v . q.  A single row with more than 2 targets of
 //       entries is cut into items whose totals k_pb_finish adds in order.
-//   reduced scatter (k_pbr_scatter): the first row bands -- the high-degree rows, where a row has many entries in
+//   reduced part of the scatter pass: the first row bands -- the high-degree rows, where a row has many entries in
 //       one column band (on the 10 M-vertex R-MAT graph the 222 M blocked entries of rows with degree >= 128 form
 //       only 37 M distinct (row, column band) pairs) -- do not pass single x values to the gather pass but partial
 //       row sums.  Their (row band, column band) runs are cut into steps of 512 entries; lane l of a wavefront takes
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64) k_pbr_count(const uint4 *rcode, u32 *cnt)
     if (threadIdx.x == 0) cnt[blockIdx.x] = n;
 }
 
-// row (in band) of every piece, at the position k_pbr_scatter writes the piece to
+// row (in band) of every piece, at the position k_pb_scatter writes the piece to
 __global__ void __launch_bounds__(64) k_pbr_rows(const uint4 *rcode, const uint4 *rrow, const u32 *step_base, uint16_t *prow)
 {
     const uint4 c = rcode[(size_t)blockIdx.x * 64 + threadIdx.x];
@@ -305,109 +305,114 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 }
 
 // ---- the per-iteration kernels --------------------------------------------------------------------------------
-// unit = {column band, first quad, last quad} in scatter order.  Each wavefront walks its own contiguous share of the
-// unit 64 quads at a time (lane = consecutive quad): contiguous loads, and 32-byte-per-lane stores that are
-// contiguous inside a run.  4 quads per lane in flight.
+// Scatter pass.  unit = {column band, first step, last step, first quad, last quad}: the workgroup stages the band's
+// LZX_PB_CB x values (plus a zero for padding) in LDS once and then walks its share of both tables.
+//   reduced part: wavefront w takes steps w, w+16, ... of the unit, four steps' loads in flight; lane = 8 consecutive
+//       entries, pieces written plane by plane, lane-compacted;
+//   plain part: each wavefront walks its own contiguous share of the quads 64 at a time (lane = consecutive quad):
+//       contiguous loads, and 32-byte-per-lane stores that are contiguous inside a run; 4 quads per lane in flight.
 __global__ void __launch_bounds__(1024)
-k_pb_scatter(const u32 *unit, const uint2 *q_lcol, const u32 *q_dst, const double *__restrict__ x, u64 xlen, double *val, int ablate)
+k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
+             const double *__restrict__ x, u64 xlen, double *val, double *val_plain, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) double tile[];   // LZX_PB_CB staged values + a zero for padding
-    const u32 band = unit[3 * blockIdx.x], beg = unit[3 * blockIdx.x + 1], end = unit[3 * blockIdx.x + 2];
+    const u32 band = unit[5 * blockIdx.x];
     const u64 base = (u64)band * LZX_PB_CB;
-    for (u32 j = threadIdx.x; j < LZX_PB_CB + 2; j += 1024) {
-        const u64 p = base + j;
-        tile[j] = (j < LZX_PB_CB && p < xlen) ? x[p] : 0.0;
-    }
-    __syncthreads();
-    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u32 span = (((end - beg) + 15u) / 16u + 63u) & ~63u;   // quads per wavefront, multiple of 64
-    const u32 wbeg = beg + wv * span;
-    const u32 wend = wbeg + span < end ? wbeg + span : end;
-    u32 j = wbeg + lane;
-    for (; j + 3 * 64 < wend; j += 4 * 64) {
-        uint2 c[4];
-        u32 d[4];
+    // staging is dead time for this CU (the tile leaves room for one workgroup): all eight 16-byte loads of a
+    // thread are issued before the first LDS write, so it costs one memory round trip
+    if (base + LZX_PB_CB <= xlen) {
+        const double2 *src = reinterpret_cast<const double2 *>(x + base);   // band starts are 128 KiB aligned
+        double2 t[LZX_PB_CB / 2048];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            c[u] = q_lcol[j + u * 64];
-            d[u] = q_dst[j + u * 64];
-        }
+        for (u32 u = 0; u < LZX_PB_CB / 2048; ++u) t[u] = src[threadIdx.x + u * 1024];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            double2 lo, hi;
-            if (ablate != 2) {
-            lo.x = tile[c[u].x & 0xffffu];
-            lo.y = tile[c[u].x >> 16];
-            hi.x = tile[c[u].y & 0xffffu];
-            hi.y = tile[c[u].y >> 16];
-            }
-            if (ablate == 2) { lo.x = c[u].x; lo.y = c[u].y; hi = lo; }
-            double2 *out = reinterpret_cast<double2 *>(val + d[u]);   // 32-byte aligned: slots of a quad
-            if (ablate == 1) { if (lo.x + lo.y + hi.x + hi.y == 1.2345e-300) out[0] = lo; continue; }
-            if (ablate == 4) out = reinterpret_cast<double2 *>(val + (size_t)(j + u * 64) * 4);
-            out[0] = lo;
-            if (ablate != 3) out[1] = hi;
-        }
+        for (u32 u = 0; u < LZX_PB_CB / 2048; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = t[u];
+    } else {
+        for (u32 j = threadIdx.x; j < LZX_PB_CB; j += 1024) tile[j] = base + j < xlen ? x[base + j] : 0.0;
     }
-    for (; j < wend; j += 64) {
-        const uint2 c = q_lcol[j];
-        double2 lo, hi;
-        lo.x = tile[c.x & 0xffffu];
-        lo.y = tile[c.x >> 16];
-        hi.x = tile[c.y & 0xffffu];
-        hi.y = tile[c.y >> 16];
-        double2 *out = reinterpret_cast<double2 *>(val + q_dst[j]);
-        out[0] = lo;
-        out[1] = hi;
-    }
-}
-
-// Reduced scatter: unit = {column band, first step, last step}; wavefront w of the workgroup takes steps w, w+16, ...
-// of the unit, four steps' loads in flight.
-__global__ void __launch_bounds__(1024)
-k_pbr_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const double *__restrict__ x, u64 xlen, double *val)
-{
-    extern __shared__ __attribute__((aligned(16))) double tile[];   // LZX_PB_CB staged values + a zero for padding
-    const u32 band = unit[3 * blockIdx.x], beg = unit[3 * blockIdx.x + 1], end = unit[3 * blockIdx.x + 2];
-    const u64 base = (u64)band * LZX_PB_CB;
-    for (u32 j = threadIdx.x; j < LZX_PB_CB + 2; j += 1024) {
-        const u64 p = base + j;
-        tile[j] = (j < LZX_PB_CB && p < xlen) ? x[p] : 0.0;
-    }
+    if (threadIdx.x < 2) tile[LZX_PB_CB + threadIdx.x] = 0.0;
     __syncthreads();
     const u32 lane = threadIdx.x & 63;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    auto body = [&](const uint4 &c, u32 pos) {
-        double xv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = tile[pbr_half(c, e) & 0x7fffu];
-        double s = 0.0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool f = pbr_flag(c, e) != 0;
-            s += xv[e];
-            const unsigned long long m = __ballot(f);
-            if (f) {
-                val[pos + lanes_below(m)] = s;
-                s = 0.0;
-            }
-            pos += (u32)__popcll(m);
-        }
-    };
     constexpr u32 W = 1024 / 64;
-    u32 s = beg + wv;
-    for (; s + 3 * W < end; s += 4 * W) {
-        uint4 c[4];
-        u32 b[4];
+
+    {   // ---- reduced bands
+        const u32 beg = unit[5 * blockIdx.x + 1], end = unit[5 * blockIdx.x + 2];
+        auto body = [&](const uint4 &c, u32 pos) {
+            double xv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            c[u] = scode[(size_t)(s + u * W) * 64 + lane];
-            b[u] = sbase[s + u * W];
+            for (int e = 0; e < 8; ++e) xv[e] = tile[pbr_half(c, e) & 0x7fffu];
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool f = pbr_flag(c, e) != 0;
+                s += xv[e];
+                const unsigned long long m = __ballot(f);
+                if (f) {
+                    val[pos + lanes_below(m)] = s;
+                    s = 0.0;
+                }
+                pos += (u32)__popcll(m);
+            }
+        };
+        u32 s = beg + wv;
+        for (; s + 3 * W < end; s += 4 * W) {
+            uint4 c[4];
+            u32 b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                b[u] = sbase[s + u * W];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) body(c[u], b[u]);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) body(c[u], b[u]);
+        for (; s < end; s += W) body(scode[(size_t)s * 64 + lane], sbase[s]);
     }
-    for (; s < end; s += W) body(scode[(size_t)s * 64 + lane], sbase[s]);
+
+    {   // ---- plain bands
+        const u32 beg = unit[5 * blockIdx.x + 3], end = unit[5 * blockIdx.x + 4];
+        const u32 span = (((end - beg) + W - 1) / W + 63u) & ~63u;   // quads per wavefront, multiple of 64
+        const u32 wbeg = beg + wv * span;
+        const u32 wend = wbeg + span < end ? wbeg + span : end;
+        u32 j = wbeg + lane;
+        for (; j + 3 * 64 < wend; j += 4 * 64) {
+            uint2 c[4];
+            u32 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c[u] = q_lcol[j + u * 64];
+                d[u] = q_dst[j + u * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double2 lo, hi;
+                if (ablate != 2) {
+                    lo.x = tile[c[u].x & 0xffffu];
+                    lo.y = tile[c[u].x >> 16];
+                    hi.x = tile[c[u].y & 0xffffu];
+                    hi.y = tile[c[u].y >> 16];
+                }
+                if (ablate == 2) { lo.x = c[u].x; lo.y = c[u].y; hi = lo; }
+                double2 *out = reinterpret_cast<double2 *>(val_plain + d[u]);   // 32-byte aligned: slots of a quad
+                if (ablate == 1) { if (lo.x + lo.y + hi.x + hi.y == 1.2345e-300) out[0] = lo; continue; }
+                if (ablate == 4) out = reinterpret_cast<double2 *>(val_plain + (size_t)(j + u * 64) * 4);
+                out[0] = lo;
+                if (ablate != 3) out[1] = hi;
+            }
+        }
+        for (; j < wend; j += 64) {
+            const uint2 c = q_lcol[j];
+            double2 lo, hi;
+            lo.x = tile[c.x & 0xffffu];
+            lo.y = tile[c.x >> 16];
+            hi.x = tile[c.y & 0xffffu];
+            hi.y = tile[c.y >> 16];
+            double2 *out = reinterpret_cast<double2 *>(val_plain + q_dst[j]);
+            out[0] = lo;
+            out[1] = hi;
+        }
+    }
 }
 
 __device__ __forceinline__ double wave_sum_pb(double v)
@@ -554,11 +559,10 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_part);
     pb_free(c->d_pbr_code);
     pb_free(c->d_pbr_base);
-    pb_free(c->d_pbr_unit);
     c->pb = false;
     c->pb_entries = c->pb_values = c->pbr_entries = c->pb_val_offset = 0;
     c->pb_units = c->pb_units0 = c->pb_nr = c->pb_gather_grid = c->pb_n_items = c->pb_n_multi = c->pb_finish_grid = 0;
-    c->pbr_steps = c->pbr_units = c->pbr_units0 = 0;
+    c->pbr_steps = 0;
 }
 
 u32 lzx_pb_partials(const lzx_ctx *c) { return c->pb ? c->pb_gather_grid + c->pb_finish_grid : 0; }
@@ -661,38 +665,53 @@ int pb_layout_runs(Arena &ar, hipStream_t st, const u64 *keys, u64 count, u32 al
     return LZX_OK;
 }
 
-// (column band, first, last) work units over something sorted by column band, at most `cap` things per unit;
-// units0 = how many of them (they are sorted by band) lie wholly inside chunk 0 of the exchange layout
-int pb_units(const lzx_ctx *c, hipStream_t st, const u32 *d_bstart, u32 nb, u32 cap, u32 **d_unit, u32 *n_units, u32 *n_units0)
+// Scatter work units {column band, first step, last step, first quad, last quad}: a band's steps (reduced part) and
+// quads (plain part) are cut into as many units as its entries need at `cap` entries per unit, each unit taking the
+// same share of both.  units0 = how many of them (they are sorted by band) lie wholly inside chunk 0 of the exchange.
+int pb_units(lzx_ctx *c, hipStream_t st, const std::vector<u32> &sstart, const std::vector<u32> &qstart, u32 nb, u32 cap)
 {
-    std::vector<u32> bstart((size_t)nb + 1), units;
-    LZX_HIP(hipMemcpyAsync(bstart.data(), d_bstart, sizeof(u32) * ((size_t)nb + 1), hipMemcpyDeviceToHost, st));
-    LZX_HIP(hipStreamSynchronize(st));
-    for (u32 b = 0; b < nb; ++b)
-        for (u32 s = bstart[b]; s < bstart[b + 1]; s += cap) {
+    std::vector<u32> units;
+    for (u32 b = 0; b < nb; ++b) {
+        const u32 s0 = sstart.empty() ? 0 : sstart[b], s1 = sstart.empty() ? 0 : sstart[b + 1];
+        const u32 q0 = qstart.empty() ? 0 : qstart[b], q1 = qstart.empty() ? 0 : qstart[b + 1];
+        const u64 entries = (u64)(s1 - s0) * LZX_PBR_STEP + (u64)(q1 - q0) * 4;
+        if (entries == 0) continue;
+        const u32 parts = (u32)((entries + cap - 1) / cap);
+        for (u32 i = 0; i < parts; ++i) {
             units.push_back(b);
-            units.push_back(s);
-            units.push_back(std::min(bstart[b + 1], s + cap));
+            units.push_back(s0 + (u32)((u64)(s1 - s0) * i / parts));
+            units.push_back(s0 + (u32)((u64)(s1 - s0) * (i + 1) / parts));
+            units.push_back(q0 + (u32)((u64)(q1 - q0) * i / parts));
+            units.push_back(q0 + (u32)((u64)(q1 - q0) * (i + 1) / parts));
         }
-    *n_units = (u32)(units.size() / 3);
-    *n_units0 = *n_units;
+    }
+    c->pb_units = (u32)(units.size() / 5);
+    c->pb_units0 = c->pb_units;
     if (c->overlap) {
         const u64 chunk0_end = (u64)c->world * c->xs0;
         u32 u0 = 0;
-        while (u0 < *n_units && ((u64)units[3 * u0] + 1) * LZX_PB_CB <= chunk0_end) ++u0;
-        *n_units0 = u0;
+        while (u0 < c->pb_units && ((u64)units[5 * u0] + 1) * LZX_PB_CB <= chunk0_end) ++u0;
+        c->pb_units0 = u0;
     }
-    LZX_TRY(pb_alloc(d_unit, units.size()));
+    LZX_TRY(pb_alloc(&c->d_pb_unit, units.size()));
     if (!units.empty())
-        LZX_HIP(hipMemcpyAsync(*d_unit, units.data(), sizeof(u32) * units.size(), hipMemcpyHostToDevice, st));
+        LZX_HIP(hipMemcpyAsync(c->d_pb_unit, units.data(), sizeof(u32) * units.size(), hipMemcpyHostToDevice, st));
+    LZX_HIP(hipStreamSynchronize(st));
+    return LZX_OK;
+}
+
+int pb_download(hipStream_t st, const u32 *d, size_t count, std::vector<u32> &h)
+{
+    h.resize(count);
+    LZX_HIP(hipMemcpyAsync(h.data(), d, sizeof(u32) * count, hipMemcpyDeviceToHost, st));
     LZX_HIP(hipStreamSynchronize(st));
     return LZX_OK;
 }
 
 // Reduced bands [0, nred): keys[0, count) sorted.  Leaves the scatter tables in c, the row of every piece in
 // prow[0, *pieces) and the first value position of every reduced band (and the end) in band_pos[0 .. nred].
-int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nred, u32 nr, u32 nb, u32 unit_cap, uint16_t *prow,
-                     std::vector<u32> &band_pos, u32 *pieces)
+int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nred, u32 nr, u32 nb, uint16_t *prow,
+                     std::vector<u32> &band_pos, u32 *pieces, std::vector<u32> &sstart)
 {
     Arena ar;
     Runs runs;
@@ -743,7 +762,7 @@ int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32
                        c->d_pbr_code, c->d_pbr_base);
     LZX_TRY(ar.get(&bstart, (u64)nb + 1));
     hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), skey_s, nsteps, nb, bstart);
-    LZX_TRY(pb_units(c, st, bstart, nb, unit_cap / LZX_PBR_STEP, &c->d_pbr_unit, &c->pbr_units, &c->pbr_units0));
+    LZX_TRY(pb_download(st, bstart, (size_t)nb + 1, sstart));
     c->pbr_steps = nsteps;
     LZX_HIP(hipStreamSynchronize(st));
     LZX_HIP(hipGetLastError());
@@ -753,8 +772,8 @@ int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32
 // Plain bands: keys[0, count) sorted (all of bands >= nred).  Leaves the quad scatter tables in c, the row of every
 // padded position in prow[0, *total_pad) and the first padded position of every band in band_pos[0 .. nr]
 // (relative to this part; bands < nred get 0).
-int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nr, u32 nb, u32 unit_cap, uint16_t *prow,
-                   std::vector<u32> &band_pos, u32 *total_pad_out)
+int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nr, u32 nb, uint16_t *prow,
+                   std::vector<u32> &band_pos, u32 *total_pad_out, std::vector<u32> &qstart)
 {
     Arena ar;
     Runs runs;
@@ -792,7 +811,7 @@ int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 n
     hipLaunchKernelGGL(k_pb_quads, GRID(nquads), qsorted, plcol, nquads, reinterpret_cast<uint2 *>(c->d_pb_lcol), c->d_pb_dst);
     LZX_TRY(ar.get(&bstart, (u64)nb + 1));
     hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), qkey_s, nquads, nb, bstart);
-    LZX_TRY(pb_units(c, st, bstart, nb, unit_cap / 4, &c->d_pb_unit, &c->pb_units, &c->pb_units0));
+    LZX_TRY(pb_download(st, bstart, (size_t)nb + 1, qstart));
     *total_pad_out = total_pad;
     LZX_HIP(hipStreamSynchronize(st));
     LZX_HIP(hipGetLastError());
@@ -814,9 +833,14 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         target = (u32)std::min<u64>(LZX_PB_TARGET, std::max<u64>(4096, (want + 1023) & ~1023ull));
     }
     if (c->pb_target_opt > 0) target = (u32)c->pb_target_opt;
-    // entries per scatter unit: at least four units per CU (each restages its 128 KiB column band, which small graphs
-    // hold in L2), at most LZX_PB_UNIT
-    const u32 unit_cap = (u32)std::min<u64>(LZX_PB_UNIT, std::max<u64>(8192, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
+    // entries per scatter unit: every unit restages its 128 KiB column band while its CU does nothing else, but small
+    // units even out the tail: 64 Ki entries (measured on C3 and its 1/4 and 1/8 rank shares, tools/rank_probe.py:
+    // 16 Ki .. 1 Mi tried, 64 Ki best or tied everywhere); smaller, down to 8 Ki, only to give every CU about four
+    // units on graphs whose x sits in the L2s anyway
+    u32 unit_cap = 65536;
+    if (c->xlen * sizeof(double) <= (16u << 20))
+        unit_cap = (u32)std::min<u64>(unit_cap, std::max<u64>(8192, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
+    if (c->pb_unit_opt > 0) unit_cap = (u32)c->pb_unit_opt;
 
     // ---- row bands: consecutive local rows (they are in descending degree order).
     //  reduced bands first: as many rows as the wave-private y tile can give enough replica slots (a row with many
@@ -878,14 +902,14 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     //    of the plain bands.  prow = row in band per position (0xffff: padding).
     const u64 plain_entries = total - red_entries;
     uint16_t *d_prow = nullptr;
-    std::vector<u32> red_pos, plain_pos;
+    std::vector<u32> red_pos, plain_pos, sstart, qstart;
     u32 pieces = 0, plain_pad = 0;
     // the sizes of both parts are only known once their runs are laid out: build each into its own array first
     uint16_t *d_prow_plain = nullptr, *d_prow_red = nullptr;
     if (red_entries) {
         LZX_TRY(ar.get(&d_prow_red, red_entries + 16));
         hipLaunchKernelGGL(k_pb_fill16, GRID(red_entries + 16), d_prow_red, red_entries + 16, (uint16_t)0xffffu);
-        LZX_TRY(pb_build_reduced(c, st, d_sorted, red_entries, nred, nr, nb, unit_cap, d_prow_red, red_pos, &pieces));
+        LZX_TRY(pb_build_reduced(c, st, d_sorted, red_entries, nred, nr, nb, d_prow_red, red_pos, &pieces, sstart));
     }
     const u32 red_len = (pieces + 7u) & ~7u;
     if (plain_entries) {
@@ -895,9 +919,10 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         if (bound >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: padded entry bound overflows");
         LZX_TRY(ar.get(&d_prow_plain, bound));
         hipLaunchKernelGGL(k_pb_fill16, GRID(bound), d_prow_plain, bound, (uint16_t)0xffffu);
-        LZX_TRY(pb_build_plain(c, st, d_sorted + red_entries, plain_entries, nr, nb, unit_cap, d_prow_plain, plain_pos, &plain_pad));
+        LZX_TRY(pb_build_plain(c, st, d_sorted + red_entries, plain_entries, nr, nb, d_prow_plain, plain_pos, &plain_pad, qstart));
     }
     ar.drop(d_sorted);
+    LZX_TRY(pb_units(c, st, sstart, qstart, nb, unit_cap));
     const u64 len = (u64)red_len + plain_pad;
     if (len >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu values do not fit 32-bit slots", (unsigned long long)len);
     LZX_TRY(ar.get(&d_prow, len + 8));
@@ -1018,24 +1043,20 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     const size_t lds1 = ((size_t)LZX_PB_CB + 2) * sizeof(double);
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    if (c->pbr_units)
-        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pbr_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    double *val_plain = c->d_pb_val + c->pb_val_offset;
-    // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
-    auto scatter = [&](u32 r0, u32 r1, u32 p0, u32 p1) {
-        if (r1 > r0)
-            hipLaunchKernelGGL(k_pbr_scatter, dim3(r1 - r0), dim3(1024), lds1, c->stream, c->d_pbr_unit + 3 * (size_t)r0,
-                               c->d_pbr_code, c->d_pbr_base, x, c->xlen, c->d_pb_val);
-        if (p1 > p0)
-            hipLaunchKernelGGL(k_pb_scatter, dim3(p1 - p0), dim3(1024), lds1, c->stream, c->d_pb_unit + 3 * (size_t)p0,
-                               reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, val_plain, getenv("LZX_ABLATE") ? atoi(getenv("LZX_ABLATE")) : 0);
+    static const int ablate = getenv("LZX_ABLATE") ? atoi(getenv("LZX_ABLATE")) : 0;
+    auto scatter = [&](u32 u0, u32 u1) {
+        if (u1 > u0)
+            hipLaunchKernelGGL(k_pb_scatter, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
+                               c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val,
+                               c->d_pb_val + c->pb_val_offset, ablate);
     };
+    // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
     if (chunk1_ready) {
-        scatter(0, c->pbr_units0, 0, c->pb_units0);
+        scatter(0, c->pb_units0);
         LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
-        scatter(c->pbr_units0, c->pbr_units, c->pb_units0, c->pb_units);
+        scatter(c->pb_units0, c->pb_units);
     } else {
-        scatter(0, c->pbr_units, 0, c->pb_units);
+        scatter(0, c->pb_units);
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
     if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into

@@ -13,8 +13,8 @@ src = pkg.Engine(0, propagation_blocking=0)
 src.gen_rmat(scale, n, draws, 1234)
 rp, ci = src.get_graph_csr()
 src.close()
-for world in (1, 2, 4, 8):
-    for opts in (dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, pb_target=16384)):
+for world in (1, 4, 8):
+    for opts in (dict(pb_unit=16384), dict(pb_unit=32768), dict(pb_unit=65536), dict(pb_unit=131072), dict(pb_unit=65536), dict(pb_unit=32768)):
         if world == 1:
             eng = pkg.Engine(0, **opts)
             eng.set_graph_csr(rp, ci)
@@ -27,6 +27,6 @@ for world in (1, 2, 4, 8):
             e0 = grp.engines[0]
         gi = e0.info()
         avg, mn = e0.bench_spmv(10)
-        print(f"world={world} {opts} rows_local={gi['rows_local']} nnz_local={gi['nnz_local']} pb={gi['pb_entries']} "
+        print(f"world={world} {opts} rows_local={gi['rows_local']} nnz_local={gi['nnz_local']} pb={gi['pb_entries']} reduced={gi['pb_reduced_entries']} values={gi['pb_values']} "
               f"spmv min {mn:.4f} ms (x{world} = {mn * world:.3f})", flush=True)
         (grp or e0).close()
