@@ -92,28 +92,44 @@ __global__ void k_pb_runstarts(const u32 *head, const u32 *runid_incl, u64 count
     if (head[i]) runstart[runid_incl[i] - 1] = (u32)i;
 }
 
-// padded run length: a multiple of `align` entries (4 = whole quads; 16 = whole 128-byte lines of values)
-__global__ void k_pb_padlen(const u32 *runstart, u32 nruns, u64 count, u32 align, u32 *padlen)
+// Per run: its format (1 = reduced: its entries cross the passes as partial row sums) and, for reduced runs, the
+// length padded to whole steps.
+__global__ void k_pb_run_format(const u32 *runstart, u32 nruns, u64 count, u32 min_run, uint8_t *fmt, u32 *epad)
 {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nruns) return;
-    const u32 end = (r + 1 < nruns) ? runstart[r + 1] : (u32)count;
-    padlen[r] = (end - runstart[r] + align - 1u) & ~(align - 1u);
+    const u32 len = ((r + 1 < nruns) ? runstart[r + 1] : (u32)count) - runstart[r];
+    const bool red = len >= min_run;
+    fmt[r] = red ? 1 : 0;
+    epad[r] = red ? ((len + LZX_PBR_STEP - 1) & ~(LZX_PBR_STEP - 1)) : 0u;
 }
 
-// place every entry at its padded position: row / column within band, and per quad its column band
-__global__ void k_pb_place(const u64 *keys, const u32 *runid_incl, const u32 *runstart, const u32 *pstart, u64 count,
-                           uint16_t *prow, uint16_t *plcol, uint16_t *quad_cband, u32 *pos_of_entry)
+// Values a run hands to the gather pass, padded to `align` (so every run starts on a 64-byte boundary): the pieces of
+// a reduced run (step_excl = exclusive scan of the pieces per step), the entries of a plain one.
+__global__ void k_pb_run_values(const u32 *runstart, u32 nruns, u64 count, const uint8_t *fmt, const u32 *estart,
+                                const u32 *step_excl, u32 align, u32 *vcount)
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nruns) return;
+    u32 n;
+    if (fmt[r]) n = step_excl[estart[r + 1] / LZX_PBR_STEP] - step_excl[estart[r] / LZX_PBR_STEP];
+    else n = ((r + 1 < nruns) ? runstart[r + 1] : (u32)count) - runstart[r];
+    vcount[r] = (n + align - 1u) & ~(align - 1u);
+}
+
+// plain runs: place every entry at its value position: row / column within band, and per quad its column band
+__global__ void k_pb_place(const u64 *keys, const u32 *runid_incl, const u32 *runstart, const u32 *vpos, const uint8_t *fmt,
+                           u64 count, uint16_t *prow, uint16_t *plcol, uint16_t *quad_cband)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const u32 r = runid_incl[i] - 1;
-    const u32 pos = pstart[r] + ((u32)i - runstart[r]);
+    if (fmt[r]) return;
+    const u32 pos = vpos[r] + ((u32)i - runstart[r]);
     const u64 k = keys[i];
     prow[pos] = (uint16_t)((k >> 14) & 0x3ffu);
     plcol[pos] = (uint16_t)(k & 0x3fffu);
     if ((pos & 3u) == 0) quad_cband[pos >> 2] = (uint16_t)((k >> 24) & 0xffffu);
-    pos_of_entry[i] = pos;
 }
 
 __global__ void k_pb_fill16(uint16_t *a, u64 count, uint16_t v)
@@ -166,12 +182,13 @@ __global__ void k_pb_bounds_u64(const u64 *keys, u64 count, u32 shift, u32 targe
     out[t] = (u32)lo;
 }
 
-// ... and the same boundaries in padded positions
-__global__ void k_pb_rstart_pad(const u32 *rstart, const u32 *pos_of_entry, u32 nr, u64 count, u32 total_pad, u32 *rstart_pad)
+// first value position of every row band (a band starts a run); bands without entries get their successor's
+__global__ void k_pb_band_pos(const u32 *rstart, const u32 *runid_incl, const u32 *vpos, u32 nr, u64 count, u32 len, u32 *band_pos)
 {
     const u32 R = blockIdx.x * blockDim.x + threadIdx.x;
     if (R > nr) return;
-    rstart_pad[R] = rstart[R] < count ? pos_of_entry[rstart[R]] : total_pad;
+    const u32 i = rstart[R];
+    band_pos[R] = i < count ? vpos[runid_incl[i] - 1] : len;
 }
 
 // Gather order (padded), step = 64 consecutive positions counted from the start of the row band.  occ[p] = how many
@@ -227,34 +244,37 @@ __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *
 
 
 // ---- reduced bands: build ------------------------------------------------------------------------------------
-// entry i of the (row band, column band, row, column)-sorted keys -> padded position (runs padded to whole steps):
-// code = column in band | 0x8000 on the last entry of a piece (same row, same 8-entry lane chunk), row in band,
-// and the column band of every step
-__global__ void k_pbr_place(const u64 *keys, const u32 *runid_incl, const u32 *runstart, const u32 *pstart, u64 count,
-                            uint16_t *rcode, uint16_t *rrow, uint16_t *step_cband)
+// reduced runs: entry i of the (row band, column band, row, column)-sorted keys -> its place in the step-padded code
+// table: code = column in band | 0x8000 on the last entry of a piece (same row, same 8-entry lane chunk), row in
+// band, and per step its column band and run
+__global__ void k_pbr_place(const u64 *keys, const u32 *runid_incl, const u32 *runstart, const u32 *estart, const uint8_t *fmt,
+                            u64 count, uint16_t *rcode, uint16_t *rrow, uint16_t *step_cband, u32 *step_run)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const u32 r = runid_incl[i] - 1;
+    if (!fmt[r]) return;
     const u32 off = (u32)i - runstart[r];
-    const u32 pos = pstart[r] + off;
+    const u32 pos = estart[r] + off;
     const u64 k = keys[i];
     const u32 lrow = (u32)((k >> 14) & 0x3ffu);
     const bool last = (off & (LZX_PBR_CHUNK - 1)) == LZX_PBR_CHUNK - 1 || i + 1 == count || runid_incl[i + 1] - 1 != r ||
                       (u32)((keys[i + 1] >> 14) & 0x3ffu) != lrow;
     rcode[pos] = (uint16_t)((k & 0x3fffu) | (last ? 0x8000u : 0u));
     rrow[pos] = (uint16_t)lrow;
-    if ((off & (LZX_PBR_STEP - 1)) == 0) step_cband[pos / LZX_PBR_STEP] = (uint16_t)((k >> 24) & 0xffffu);
+    if ((off & (LZX_PBR_STEP - 1)) == 0) {
+        step_cband[pos / LZX_PBR_STEP] = (uint16_t)((k >> 24) & 0xffffu);
+        step_run[pos / LZX_PBR_STEP] = r;
+    }
 }
 
-// first step of every reduced band (a band starts a run, a run starts a step)
-__global__ void k_pbr_band_step(const u32 *rstart, const u32 *runid_incl, const u32 *pstart, u32 nred, u64 count,
-                                u32 nsteps, u32 *band_step)
+// first value slot of every step: its run's first slot + the pieces of the run's earlier steps
+__global__ void k_pbr_step_base(const u32 *step_run, const u32 *estart, const u32 *step_excl, const u32 *vpos, u32 nsteps, u32 *step_base)
 {
-    const u32 R = blockIdx.x * blockDim.x + threadIdx.x;
-    if (R > nred) return;
-    const u32 i = rstart[R];
-    band_step[R] = i < count ? pstart[runid_incl[i] - 1] / LZX_PBR_STEP : nsteps;
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsteps) return;
+    const u32 r = step_run[s];
+    step_base[s] = vpos[r] + step_excl[s] - step_excl[estart[r] / LZX_PBR_STEP];
 }
 
 __device__ __forceinline__ u32 pbr_flag(const uint4 &c, int e)
@@ -630,41 +650,6 @@ int pb_scan(hipStream_t st, bool inclusive, u32 *in, u32 *out, u64 count)
     return LZX_OK;
 }
 
-// runs = maximal stretches of one (row band, column band) in sorted keys; each padded to a multiple of `align`
-struct Runs {
-    u32 *runid = nullptr, *runstart = nullptr, *pstart = nullptr;   // [count] inclusive run number; [nruns+1]; [nruns+1] padded start
-    u32 nruns = 0, total_pad = 0;
-};
-int pb_layout_runs(Arena &ar, hipStream_t st, const u64 *keys, u64 count, u32 align, Runs &r)
-{
-    u32 *head = nullptr, *padlen = nullptr;
-    LZX_TRY(ar.get(&head, count));
-    LZX_TRY(ar.get(&r.runid, count));
-    hipLaunchKernelGGL(k_pb_heads, GRID(count), keys, count, head);
-    LZX_TRY(pb_scan(st, true, head, r.runid, count));
-    LZX_HIP(hipMemcpy(&r.nruns, r.runid + (count - 1), sizeof(u32), hipMemcpyDeviceToHost));
-    LZX_TRY(ar.get(&r.runstart, (u64)r.nruns + 1));
-    LZX_TRY(ar.get(&padlen, (u64)r.nruns + 1));
-    LZX_TRY(ar.get(&r.pstart, (u64)r.nruns + 1));
-    hipLaunchKernelGGL(k_pb_runstarts, GRID(count), head, r.runid, count, r.runstart);
-    LZX_HIP(hipMemsetAsync(padlen + r.nruns, 0, sizeof(u32), st));
-    hipLaunchKernelGGL(k_pb_padlen, GRID(r.nruns), r.runstart, r.nruns, count, align, padlen);
-    // 64-bit check of the padded total before the 32-bit scan
-    {
-        std::vector<u32> h((size_t)r.nruns);
-        LZX_HIP(hipMemcpyAsync(h.data(), padlen, sizeof(u32) * r.nruns, hipMemcpyDeviceToHost, st));
-        LZX_HIP(hipStreamSynchronize(st));
-        u64 sum = 0;
-        for (u32 v : h) sum += v;
-        if (sum >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu padded entries do not fit 32-bit slots", (unsigned long long)sum);
-    }
-    LZX_TRY(pb_scan(st, false, padlen, r.pstart, (u64)r.nruns + 1));
-    LZX_HIP(hipMemcpy(&r.total_pad, r.pstart + r.nruns, sizeof(u32), hipMemcpyDeviceToHost));
-    ar.drop(head);
-    ar.drop(padlen);
-    return LZX_OK;
-}
-
 // Scatter work units {column band, first step, last step, first quad, last quad}: a band's steps (reduced part) and
 // quads (plain part) are cut into as many units as its entries need at `cap` entries per unit, each unit taking the
 // same share of both.  units0 = how many of them (they are sorted by band) lie wholly inside chunk 0 of the exchange.
@@ -708,116 +693,6 @@ int pb_download(hipStream_t st, const u32 *d, size_t count, std::vector<u32> &h)
     return LZX_OK;
 }
 
-// Reduced bands [0, nred): keys[0, count) sorted.  Leaves the scatter tables in c, the row of every piece in
-// prow[0, *pieces) and the first value position of every reduced band (and the end) in band_pos[0 .. nred].
-int pb_build_reduced(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nred, u32 nr, u32 nb, uint16_t *prow,
-                     std::vector<u32> &band_pos, u32 *pieces, std::vector<u32> &sstart)
-{
-    Arena ar;
-    Runs runs;
-    LZX_TRY(pb_layout_runs(ar, st, keys, count, LZX_PBR_STEP, runs));
-    const u32 nsteps = runs.total_pad / LZX_PBR_STEP;
-    uint16_t *rcode = nullptr, *rrow = nullptr, *step_cband = nullptr;
-    LZX_TRY(ar.get(&rcode, (u64)runs.total_pad + 8));
-    LZX_TRY(ar.get(&rrow, (u64)runs.total_pad + 8));
-    LZX_TRY(ar.get(&step_cband, (u64)nsteps + 1));
-    hipLaunchKernelGGL(k_pb_fill16, GRID(runs.total_pad), rcode, runs.total_pad, (uint16_t)LZX_PB_CB);   // padding: the zero slot, no flag
-    hipLaunchKernelGGL(k_pb_fill16, GRID(runs.total_pad), rrow, runs.total_pad, (uint16_t)0xffffu);
-    hipLaunchKernelGGL(k_pbr_place, GRID(count), keys, runs.runid, runs.runstart, runs.pstart, count, rcode, rrow, step_cband);
-    // first step of each reduced band
-    u32 *rstart = nullptr, *band_step = nullptr;
-    LZX_TRY(ar.get(&rstart, (u64)nr + 1));
-    LZX_TRY(ar.get(&band_step, (u64)nred + 1));
-    hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), keys, count, 40u, nr, rstart);
-    hipLaunchKernelGGL(k_pbr_band_step, GRID(nred + 1), rstart, runs.runid, runs.pstart, nred, count, nsteps, band_step);
-    LZX_HIP(hipStreamSynchronize(st));
-    ar.drop(runs.runid); ar.drop(runs.runstart); ar.drop(runs.pstart); ar.drop(rstart);
-    // pieces per step -> first value slot of each step (gather order = step order here)
-    u32 *step_cnt = nullptr, *step_base = nullptr;
-    LZX_TRY(ar.get(&step_cnt, (u64)nsteps + 1));
-    LZX_TRY(ar.get(&step_base, (u64)nsteps + 1));
-    LZX_HIP(hipMemsetAsync(step_cnt + nsteps, 0, sizeof(u32), st));
-    hipLaunchKernelGGL(k_pbr_count, dim3(nsteps), dim3(64), 0, st, reinterpret_cast<const uint4 *>(rcode), step_cnt);
-    LZX_TRY(pb_scan(st, false, step_cnt, step_base, (u64)nsteps + 1));
-    hipLaunchKernelGGL(k_pbr_rows, dim3(nsteps), dim3(64), 0, st, reinterpret_cast<const uint4 *>(rcode),
-                       reinterpret_cast<const uint4 *>(rrow), step_base, prow);
-    {
-        std::vector<u32> h_step((size_t)nred + 1), h_base((size_t)nsteps + 1);
-        LZX_HIP(hipMemcpyAsync(h_step.data(), band_step, sizeof(u32) * ((size_t)nred + 1), hipMemcpyDeviceToHost, st));
-        LZX_HIP(hipMemcpyAsync(h_base.data(), step_base, sizeof(u32) * ((size_t)nsteps + 1), hipMemcpyDeviceToHost, st));
-        LZX_HIP(hipStreamSynchronize(st));
-        band_pos.resize((size_t)nred + 1);
-        for (u32 R = 0; R <= nred; ++R) band_pos[R] = h_base[h_step[R]];
-        *pieces = h_base[nsteps];
-    }
-    ar.drop(rrow); ar.drop(step_cnt); ar.drop(band_step);
-    // scatter order: steps sorted (stably) by column band
-    u32 *skey = nullptr, *skey_s = nullptr, *sidx = nullptr, *ssorted = nullptr, *bstart = nullptr;
-    LZX_TRY(ar.get(&skey, nsteps)); LZX_TRY(ar.get(&skey_s, nsteps)); LZX_TRY(ar.get(&sidx, nsteps)); LZX_TRY(ar.get(&ssorted, nsteps));
-    hipLaunchKernelGGL(k_pb_iota_widen, GRID(nsteps), step_cband, nsteps, skey, sidx);
-    LZX_TRY(pb_sort_pairs16(st, skey, skey_s, sidx, ssorted, nsteps));
-    LZX_TRY(pb_alloc(&c->d_pbr_code, (u64)nsteps * 64 + 1));
-    LZX_TRY(pb_alloc(&c->d_pbr_base, (u64)nsteps + 1));
-    hipLaunchKernelGGL(k_pbr_steps, dim3(nsteps), dim3(64), 0, st, ssorted, reinterpret_cast<const uint4 *>(rcode), step_base,
-                       c->d_pbr_code, c->d_pbr_base);
-    LZX_TRY(ar.get(&bstart, (u64)nb + 1));
-    hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), skey_s, nsteps, nb, bstart);
-    LZX_TRY(pb_download(st, bstart, (size_t)nb + 1, sstart));
-    c->pbr_steps = nsteps;
-    LZX_HIP(hipStreamSynchronize(st));
-    LZX_HIP(hipGetLastError());
-    return LZX_OK;
-}
-
-// Plain bands: keys[0, count) sorted (all of bands >= nred).  Leaves the quad scatter tables in c, the row of every
-// padded position in prow[0, *total_pad) and the first padded position of every band in band_pos[0 .. nr]
-// (relative to this part; bands < nred get 0).
-int pb_build_plain(lzx_ctx *c, hipStream_t st, const u64 *keys, u64 count, u32 nr, u32 nb, uint16_t *prow,
-                   std::vector<u32> &band_pos, u32 *total_pad_out, std::vector<u32> &qstart)
-{
-    Arena ar;
-    Runs runs;
-    const u32 run_align = (c->pb_align_opt == 8 || c->pb_align_opt == 16 || c->pb_align_opt == 4) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
-    LZX_TRY(pb_layout_runs(ar, st, keys, count, run_align, runs));
-    const u32 total_pad = runs.total_pad;
-    const u64 nquads = total_pad / 4;
-    // padded positions: row / column in band per position (0xffff / column "CB" = the zero behind the staged band
-    // for padding), column band per quad
-    uint16_t *plcol = nullptr, *qcband = nullptr;
-    u32 *pos = nullptr, *rstart = nullptr, *rstart_pad = nullptr;
-    LZX_TRY(ar.get(&plcol, (u64)total_pad + 8)); LZX_TRY(ar.get(&qcband, nquads + 2)); LZX_TRY(ar.get(&pos, count));
-    hipLaunchKernelGGL(k_pb_fill16, GRID(total_pad), plcol, total_pad, (uint16_t)LZX_PB_CB);
-    hipLaunchKernelGGL(k_pb_fill16, GRID(nquads + 2), qcband, nquads + 2, (uint16_t)0xffffu);   // all-padding quads: no band
-    hipLaunchKernelGGL(k_pb_place, GRID(count), keys, runs.runid, runs.runstart, runs.pstart, count, prow, plcol, qcband, pos);
-    LZX_TRY(ar.get(&rstart, (u64)nr + 1)); LZX_TRY(ar.get(&rstart_pad, (u64)nr + 1));
-    hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), keys, count, 40u, nr, rstart);
-    hipLaunchKernelGGL(k_pb_rstart_pad, GRID(nr + 1), rstart, pos, nr, count, total_pad, rstart_pad);
-    band_pos.resize((size_t)nr + 1);
-    LZX_HIP(hipMemcpyAsync(band_pos.data(), rstart_pad, sizeof(u32) * ((size_t)nr + 1), hipMemcpyDeviceToHost, st));
-    LZX_HIP(hipStreamSynchronize(st));
-    ar.drop(runs.runid); ar.drop(runs.runstart); ar.drop(runs.pstart); ar.drop(pos); ar.drop(rstart); ar.drop(rstart_pad);
-    // scatter order: quads sorted (stably) by column band
-    u32 *qkey = nullptr, *qkey_s = nullptr, *qidx = nullptr, *qsorted = nullptr, *bstart = nullptr;
-    LZX_TRY(ar.get(&qkey, nquads)); LZX_TRY(ar.get(&qkey_s, nquads)); LZX_TRY(ar.get(&qidx, nquads)); LZX_TRY(ar.get(&qsorted, nquads));
-    hipLaunchKernelGGL(k_pb_iota_widen, GRID(nquads), qcband, nquads, qkey, qidx);
-    LZX_TRY(pb_sort_pairs16(st, qkey, qkey_s, qidx, qsorted, nquads));
-    ar.drop(qkey); ar.drop(qidx); ar.drop(qcband);
-    {
-        uint2 *q_lcol = nullptr;
-        LZX_TRY(pb_alloc(&q_lcol, nquads + 1));
-        c->d_pb_lcol = reinterpret_cast<uint16_t *>(q_lcol);
-    }
-    LZX_TRY(pb_alloc(&c->d_pb_dst, nquads + 1));
-    hipLaunchKernelGGL(k_pb_quads, GRID(nquads), qsorted, plcol, nquads, reinterpret_cast<uint2 *>(c->d_pb_lcol), c->d_pb_dst);
-    LZX_TRY(ar.get(&bstart, (u64)nb + 1));
-    hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), qkey_s, nquads, nb, bstart);
-    LZX_TRY(pb_download(st, bstart, (size_t)nb + 1, qstart));
-    *total_pad_out = total_pad;
-    LZX_HIP(hipStreamSynchronize(st));
-    LZX_HIP(hipGetLastError());
-    return LZX_OK;
-}
-
 int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, const u32 *d_deg_local,
                     const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total)
 {
@@ -842,36 +717,26 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         unit_cap = (u32)std::min<u64>(unit_cap, std::max<u64>(8192, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
     if (c->pb_unit_opt > 0) unit_cap = (u32)c->pb_unit_opt;
 
-    // ---- row bands: consecutive local rows (they are in descending degree order).
-    //  reduced bands first: as many rows as the wave-private y tile can give enough replica slots (a row with many
-    //      entries per column band sends many pieces in a row to the same slot), for as long as the band's runs stay
-    //      long enough to be cut into whole steps;
-    //  plain bands after them: closed at ~target entries or LZX_PB_RB rows.
+    // ---- row bands: consecutive local rows (they are in descending degree order): as many rows as the wave-private
+    //      y tile can give enough replica slots -- a row with many entries per column band sends many pieces in a row
+    //      to the same slot -- so 16 rows at the very top, LZX_PB_RB rows from a few thousand entries per row down.
+    //      (Option pb_reduce = 0, everything plain: closed at ~target entries instead, one gather item per band.)
+    const bool reduce = c->pb_reduce_opt != 0;
+    const u32 min_run = !reduce ? 0xffffffffu : c->pb_reduce_opt > 1 ? (u32)c->pb_reduce_opt : LZX_PBR_MIN_RUN;
     std::vector<u32> row0;
     row0.push_back(0);
-    u32 nred = 0;
-    u64 red_entries = 0;
-    u32 l = 0;
-    if (c->pb_reduce_opt != 0) {
-        const u64 min_run = c->pb_reduce_opt > 1 ? (u64)c->pb_reduce_opt : LZX_PBR_MIN_RUN;
+    if (reduce) {
+        u32 l = 0;
         while (l < c->n_loc_real) {
             u32 rep = 1;
             while (rep < 64 && (u64)rep * 2 * nb < h_nh[l]) rep <<= 1;
-            const u32 rows_max = LZX_PB_RB / rep;
-            u64 e = 0;
-            u32 r = 0;
-            while (r < rows_max && l + r < c->n_loc_real) e += h_nh[l + r++];
-            if (e < min_run * nb) break;
-            l += r;
+            l = (u32)std::min<u64>((u64)l + LZX_PB_RB / rep, c->n_loc_real);
             row0.push_back(l);
-            red_entries += e;
-            ++nred;
         }
-    }
-    {
+    } else {
         u32 rows = 0;
         u64 cnt = 0;
-        for (; l < c->n_loc_real; ++l) {
+        for (u32 l = 0; l < c->n_loc_real; ++l) {
             const u32 nh = h_nh[l];
             if (rows > 0 && (cnt + nh > target || rows == LZX_PB_RB)) {
                 row0.push_back(l);
@@ -881,15 +746,16 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             ++rows;
             cnt += nh;
         }
-        if (rows > 0 || row0.size() == 1) row0.push_back(c->n_loc_real);
+        if (rows > 0) row0.push_back(c->n_loc_real);
     }
+    if (row0.size() == 1) row0.push_back(c->n_loc_real);
     const u32 nr = (u32)row0.size() - 1;
     if (nr >= (1u << 24)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u row bands (limit 2^24)", nr);
     LZX_TRY(pb_alloc(&c->d_pb_row0, (u64)nr + 1));
     LZX_HIP(hipMemcpyAsync(c->d_pb_row0, row0.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
 
     Arena ar;
-    // 1. emit + sort by (row band, column band, row, column): the gather order; the reduced bands' entries come first
+    // 1. emit + sort by (row band, column band, row, column): the gather order
     u64 *d_keys = nullptr, *d_sorted = nullptr;
     LZX_TRY(ar.get(&d_keys, total)); LZX_TRY(ar.get(&d_sorted, total));
     if (c->n_loc_real)
@@ -898,48 +764,162 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(pb_sort_keys(st, d_keys, d_sorted, total));
     ar.drop(d_keys);
 
-    // 2. value positions.  [0, red_len): pieces of the reduced bands; [red_len, red_len + plain_pad): padded entries
-    //    of the plain bands.  prow = row in band per position (0xffff: padding).
-    const u64 plain_entries = total - red_entries;
-    uint16_t *d_prow = nullptr;
-    std::vector<u32> red_pos, plain_pos, sstart, qstart;
-    u32 pieces = 0, plain_pad = 0;
-    // the sizes of both parts are only known once their runs are laid out: build each into its own array first
-    uint16_t *d_prow_plain = nullptr, *d_prow_red = nullptr;
-    if (red_entries) {
-        LZX_TRY(ar.get(&d_prow_red, red_entries + 16));
-        hipLaunchKernelGGL(k_pb_fill16, GRID(red_entries + 16), d_prow_red, red_entries + 16, (uint16_t)0xffffu);
-        LZX_TRY(pb_build_reduced(c, st, d_sorted, red_entries, nred, nr, nb, d_prow_red, red_pos, &pieces, sstart));
+    // 2. runs = maximal stretches of one (row band, column band).  A run of at least min_run entries is REDUCED (cut
+    //    into steps, its rows' partial sums cross the passes), a shorter one PLAIN (its x values do).  On R-MAT graphs
+    //    the long runs are those of the high-degree rows and, for every row band, those of the most popular columns.
+    u32 *d_head = nullptr, *d_runid = nullptr, *d_runstart = nullptr, *d_epad = nullptr, *d_estart = nullptr;
+    uint8_t *d_fmt = nullptr;
+    u32 nruns = 0, epad_total = 0;
+    LZX_TRY(ar.get(&d_head, total)); LZX_TRY(ar.get(&d_runid, total));
+    hipLaunchKernelGGL(k_pb_heads, GRID(total), d_sorted, total, d_head);
+    LZX_TRY(pb_scan(st, true, d_head, d_runid, total));
+    LZX_HIP(hipMemcpy(&nruns, d_runid + (total - 1), sizeof(u32), hipMemcpyDeviceToHost));
+    LZX_TRY(ar.get(&d_runstart, (u64)nruns + 1)); LZX_TRY(ar.get(&d_epad, (u64)nruns + 1)); LZX_TRY(ar.get(&d_estart, (u64)nruns + 1));
+    LZX_TRY(ar.get(&d_fmt, (u64)nruns + 1));
+    hipLaunchKernelGGL(k_pb_runstarts, GRID(total), d_head, d_runid, total, d_runstart);
+    ar.drop(d_head);
+    LZX_HIP(hipMemsetAsync(d_epad + nruns, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_pb_run_format, GRID(nruns), d_runstart, nruns, total, min_run, d_fmt, d_epad);
+    {   // 64-bit check before the 32-bit scan
+        std::vector<u32> h;
+        LZX_TRY(pb_download(st, d_epad, nruns, h));
+        u64 sum = 0;
+        for (u32 v : h) sum += v;
+        if (sum >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu padded entries do not fit 32-bit slots", (unsigned long long)sum);
+        epad_total = (u32)sum;
     }
-    const u32 red_len = (pieces + 7u) & ~7u;
-    if (plain_entries) {
-        // upper bound of the padded size: every run gains < 16 entries and there are at most min(entries, nr * nb) runs
-        const u64 max_runs = std::min<u64>(plain_entries, (u64)nr * nb);
-        const u64 bound = plain_entries + max_runs * 15 + 16;
-        if (bound >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: padded entry bound overflows");
-        LZX_TRY(ar.get(&d_prow_plain, bound));
-        hipLaunchKernelGGL(k_pb_fill16, GRID(bound), d_prow_plain, bound, (uint16_t)0xffffu);
-        LZX_TRY(pb_build_plain(c, st, d_sorted + red_entries, plain_entries, nr, nb, d_prow_plain, plain_pos, &plain_pad, qstart));
-    }
-    ar.drop(d_sorted);
-    LZX_TRY(pb_units(c, st, sstart, qstart, nb, unit_cap));
-    const u64 len = (u64)red_len + plain_pad;
-    if (len >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu values do not fit 32-bit slots", (unsigned long long)len);
-    LZX_TRY(ar.get(&d_prow, len + 8));
-    hipLaunchKernelGGL(k_pb_fill16, GRID(len + 8), d_prow, len + 8, (uint16_t)0xffffu);
-    if (pieces) LZX_HIP(hipMemcpyAsync(d_prow, d_prow_red, sizeof(uint16_t) * pieces, hipMemcpyDeviceToDevice, st));
-    if (plain_pad) LZX_HIP(hipMemcpyAsync(d_prow + red_len, d_prow_plain, sizeof(uint16_t) * plain_pad, hipMemcpyDeviceToDevice, st));
-    LZX_HIP(hipStreamSynchronize(st));
-    ar.drop(d_prow_red); ar.drop(d_prow_plain);
-    // first position of every band
-    std::vector<u32> rstart((size_t)nr + 1);
-    for (u32 R = 0; R <= nr; ++R) {
-        if (R < nred) rstart[R] = red_pos[R];
-        else rstart[R] = red_len + (plain_entries ? plain_pos[R] : 0u);
-    }
-    rstart[nr] = (u32)len;
+    LZX_TRY(pb_scan(st, false, d_epad, d_estart, (u64)nruns + 1));
+    ar.drop(d_epad);
+    const u32 nsteps = epad_total / LZX_PBR_STEP;
 
-    // 3. conflict-free LDS slots for the gather pass
+    // 3. reduced runs: code table in gather (row band major) order, pieces per step
+    uint16_t *d_rcode = nullptr, *d_rrow = nullptr, *d_step_cband = nullptr;
+    u32 *d_step_run = nullptr, *d_step_cnt = nullptr, *d_step_excl = nullptr;
+    LZX_TRY(ar.get(&d_rcode, (u64)epad_total + 8)); LZX_TRY(ar.get(&d_rrow, (u64)epad_total + 8));
+    LZX_TRY(ar.get(&d_step_cband, (u64)nsteps + 1)); LZX_TRY(ar.get(&d_step_run, (u64)nsteps + 1));
+    LZX_TRY(ar.get(&d_step_cnt, (u64)nsteps + 1)); LZX_TRY(ar.get(&d_step_excl, (u64)nsteps + 1));
+    if (nsteps) {
+        hipLaunchKernelGGL(k_pb_fill16, GRID(epad_total), d_rcode, epad_total, (uint16_t)LZX_PB_CB);   // padding: the zero slot, no flag
+        hipLaunchKernelGGL(k_pb_fill16, GRID(epad_total), d_rrow, epad_total, (uint16_t)0xffffu);
+        hipLaunchKernelGGL(k_pbr_place, GRID(total), d_sorted, d_runid, d_runstart, d_estart, d_fmt, total, d_rcode, d_rrow,
+                           d_step_cband, d_step_run);
+        hipLaunchKernelGGL(k_pbr_count, dim3(nsteps), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_rcode), d_step_cnt);
+    }
+    LZX_HIP(hipMemsetAsync(d_step_cnt + nsteps, 0, sizeof(u32), st));
+    LZX_TRY(pb_scan(st, false, d_step_cnt, d_step_excl, (u64)nsteps + 1));
+    ar.drop(d_step_cnt);
+
+    // 4. value positions: every run gets its values (pieces or entries) padded to whole 64-byte lines, in gather order
+    const u32 run_align = (c->pb_align_opt == 8 || c->pb_align_opt == 16 || c->pb_align_opt == 4) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
+    u32 *d_vcount = nullptr, *d_vpos = nullptr;
+    LZX_TRY(ar.get(&d_vcount, (u64)nruns + 1)); LZX_TRY(ar.get(&d_vpos, (u64)nruns + 1));
+    LZX_HIP(hipMemsetAsync(d_vcount + nruns, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_pb_run_values, GRID(nruns), d_runstart, nruns, total, d_fmt, d_estart, d_step_excl, run_align, d_vcount);
+    u64 len = 0, red_entries = 0;
+    {
+        std::vector<u32> h;
+        LZX_TRY(pb_download(st, d_vcount, nruns, h));
+        for (u32 v : h) len += v;
+        if (len >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu values do not fit 32-bit slots", (unsigned long long)len);
+    }
+    LZX_TRY(pb_scan(st, false, d_vcount, d_vpos, (u64)nruns + 1));
+    ar.drop(d_vcount);
+    const u64 nquads = len / 4;
+    uint16_t *d_prow = nullptr, *d_plcol = nullptr, *d_qcband = nullptr;
+    u32 *d_step_base = nullptr;
+    LZX_TRY(ar.get(&d_prow, len + 8)); LZX_TRY(ar.get(&d_plcol, len + 8)); LZX_TRY(ar.get(&d_qcband, nquads + 2));
+    LZX_TRY(ar.get(&d_step_base, (u64)nsteps + 1));
+    hipLaunchKernelGGL(k_pb_fill16, GRID(len + 8), d_prow, len + 8, (uint16_t)0xffffu);        // padding: no row
+    hipLaunchKernelGGL(k_pb_fill16, GRID(len + 8), d_plcol, len + 8, (uint16_t)LZX_PB_CB);     // padding: the zero behind the staged band
+    hipLaunchKernelGGL(k_pb_fill16, GRID(nquads + 2), d_qcband, nquads + 2, (uint16_t)0xffffu);   // quads outside plain runs: no band
+    if (nsteps) {
+        hipLaunchKernelGGL(k_pbr_step_base, GRID(nsteps), d_step_run, d_estart, d_step_excl, d_vpos, nsteps, d_step_base);
+        hipLaunchKernelGGL(k_pbr_rows, dim3(nsteps), dim3(64), 0, st, reinterpret_cast<const uint4 *>(d_rcode),
+                           reinterpret_cast<const uint4 *>(d_rrow), d_step_base, d_prow);
+    }
+    hipLaunchKernelGGL(k_pb_place, GRID(total), d_sorted, d_runid, d_runstart, d_vpos, d_fmt, total, d_prow, d_plcol, d_qcband);
+    // first position of every band
+    std::vector<u32> rstart;
+    {
+        u32 *d_rstart = nullptr, *d_band_pos = nullptr;
+        LZX_TRY(ar.get(&d_rstart, (u64)nr + 1)); LZX_TRY(ar.get(&d_band_pos, (u64)nr + 1));
+        hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), d_sorted, total, 40u, nr, d_rstart);
+        hipLaunchKernelGGL(k_pb_band_pos, GRID(nr + 1), d_rstart, d_runid, d_vpos, nr, total, (u32)len, d_band_pos);
+        LZX_TRY(pb_download(st, d_band_pos, (size_t)nr + 1, rstart));
+        ar.drop(d_rstart); ar.drop(d_band_pos);
+    }
+    if (getenv("LZX_PB_STATS")) {   // run-length histogram (entries per class), for DESIGN.md
+        std::vector<u32> rs;
+        LZX_TRY(pb_download(st, d_runstart, nruns, rs));
+        u64 cls[14] = {0}, cnt[14] = {0};
+        for (u32 r = 0; r < nruns; ++r) {
+            const u32 rl = (r + 1 < nruns ? rs[r + 1] : (u32)total) - rs[r];
+            u32 b = 0;
+            while ((2u << b) <= rl && b < 13) ++b;
+            cls[b] += rl;
+            ++cnt[b];
+        }
+        for (u32 b = 0; b < 14; ++b)
+            fprintf(stderr, "[lzx pb stats] runs of %u..%u entries: %llu runs, %llu entries (%.1f %%)\n", 1u << b, (2u << b) - 1,
+                    (unsigned long long)cnt[b], (unsigned long long)cls[b], 100.0 * cls[b] / (double)total);
+    }
+    {   // entries of the reduced runs (reporting only)
+        std::vector<u32> rs;
+        std::vector<uint8_t> fm(nruns);
+        LZX_TRY(pb_download(st, d_runstart, nruns, rs));
+        LZX_HIP(hipMemcpy(fm.data(), d_fmt, nruns, hipMemcpyDeviceToHost));
+        for (u32 r = 0; r < nruns; ++r)
+            if (fm[r]) red_entries += (r + 1 < nruns ? rs[r + 1] : (u32)total) - rs[r];
+    }
+    LZX_HIP(hipStreamSynchronize(st));
+    ar.drop(d_sorted); ar.drop(d_runid); ar.drop(d_runstart); ar.drop(d_estart); ar.drop(d_fmt); ar.drop(d_vpos);
+    ar.drop(d_rrow); ar.drop(d_step_run); ar.drop(d_step_excl);
+
+    // 5. scatter order: steps and quads sorted (stably) by column band
+    std::vector<u32> sstart, qstart;
+    if (nsteps) {
+        u32 *skey = nullptr, *skey_s = nullptr, *sidx = nullptr, *ssorted = nullptr, *bstart = nullptr;
+        LZX_TRY(ar.get(&skey, nsteps)); LZX_TRY(ar.get(&skey_s, nsteps)); LZX_TRY(ar.get(&sidx, nsteps)); LZX_TRY(ar.get(&ssorted, nsteps));
+        hipLaunchKernelGGL(k_pb_iota_widen, GRID(nsteps), d_step_cband, nsteps, skey, sidx);
+        LZX_TRY(pb_sort_pairs16(st, skey, skey_s, sidx, ssorted, nsteps));
+        LZX_TRY(pb_alloc(&c->d_pbr_code, (u64)nsteps * 64 + 1));
+        LZX_TRY(pb_alloc(&c->d_pbr_base, (u64)nsteps + 1));
+        hipLaunchKernelGGL(k_pbr_steps, dim3(nsteps), dim3(64), 0, st, ssorted, reinterpret_cast<const uint4 *>(d_rcode), d_step_base,
+                           c->d_pbr_code, c->d_pbr_base);
+        LZX_TRY(ar.get(&bstart, (u64)nb + 1));
+        hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), skey_s, nsteps, nb, bstart);
+        LZX_TRY(pb_download(st, bstart, (size_t)nb + 1, sstart));
+        ar.drop(skey); ar.drop(skey_s); ar.drop(sidx); ar.drop(ssorted); ar.drop(bstart);
+    }
+    ar.drop(d_rcode); ar.drop(d_step_cband); ar.drop(d_step_base);
+    c->pbr_steps = nsteps;
+    if (nquads) {
+        u32 *qkey = nullptr, *qkey_s = nullptr, *qidx = nullptr, *qsorted = nullptr, *bstart = nullptr;
+        LZX_TRY(ar.get(&qkey, nquads)); LZX_TRY(ar.get(&qkey_s, nquads)); LZX_TRY(ar.get(&qidx, nquads)); LZX_TRY(ar.get(&qsorted, nquads));
+        hipLaunchKernelGGL(k_pb_iota_widen, GRID(nquads), d_qcband, nquads, qkey, qidx);
+        LZX_TRY(pb_sort_pairs16(st, qkey, qkey_s, qidx, qsorted, nquads));
+        ar.drop(qkey); ar.drop(qidx);
+        // quads that belong to no plain run carry key 0xffff and sort behind every band
+        LZX_TRY(ar.get(&bstart, (u64)nb + 1));
+        hipLaunchKernelGGL(k_pb_bounds_u32, GRID(nb + 1), qkey_s, nquads, nb, bstart);
+        LZX_TRY(pb_download(st, bstart, (size_t)nb + 1, qstart));
+        const u64 live = qstart[nb];
+        {
+            uint2 *q_lcol = nullptr;
+            LZX_TRY(pb_alloc(&q_lcol, live + 1));
+            c->d_pb_lcol = reinterpret_cast<uint16_t *>(q_lcol);
+        }
+        LZX_TRY(pb_alloc(&c->d_pb_dst, live + 1));
+        if (live)
+            hipLaunchKernelGGL(k_pb_quads, GRID(live), qsorted, d_plcol, live, reinterpret_cast<uint2 *>(c->d_pb_lcol), c->d_pb_dst);
+        LZX_HIP(hipStreamSynchronize(st));
+        ar.drop(qkey_s); ar.drop(qsorted); ar.drop(bstart);
+    }
+    ar.drop(d_plcol); ar.drop(d_qcband);
+    LZX_TRY(pb_units(c, st, sstart, qstart, nb, unit_cap));
+    LZX_HIP(hipGetLastError());
+
+    // 6. conflict-free LDS slots for the gather pass
     u32 *d_rstart_pad = nullptr, *d_step0 = nullptr;
     uint8_t *d_occ = nullptr;
     LZX_TRY(ar.get(&d_rstart_pad, (u64)nr + 1));
@@ -973,7 +953,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         LZX_HIP(hipStreamSynchronize(st));
     }
 
-    // 4. gather items: one per band; a band above 2 targets of values is cut into about target-sized items whose
+    // 7. gather items: one per band; a band above 2 targets of values is cut into about target-sized items whose
     //    per-row totals k_pb_finish adds in item order
     std::vector<u32> items, multi;
     u64 slots = 0;
@@ -1015,7 +995,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     c->pb_entries = total;
     c->pbr_entries = red_entries;
     c->pb_values = len;
-    c->pb_val_offset = red_len;
+    c->pb_val_offset = 0;
     c->pb_nr = nr;
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2, std::max(1u, (c->pb_n_items + waves_per_wg - 1) / waves_per_wg));
