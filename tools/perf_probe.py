@@ -52,6 +52,8 @@ if __name__ == "__main__":
         opts = [dict(), dict(propagation_blocking=1), dict(propagation_blocking=1, pb_reduce=128), dict(propagation_blocking=1, pb_reduce=64), dict(propagation_blocking=1, pb_target=2048), dict(propagation_blocking=1, hub_entries=8192)]
     if "side" in sets:
         opts = [dict(), dict(side_stream=0), dict(), dict(side_stream=0)]
+    if "tune2" in sets:
+        opts = [dict(), dict(pb_target=4096), dict(pb_target=8192), dict(pb_target=32768), dict(pb_reduce=128), dict(pb_reduce=192), dict(pb_reduce=256), dict()]
     if "one" in sets:
         opts = [dict(pb_reduce=0)]
     if "phase" in sets:

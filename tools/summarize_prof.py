@@ -1,5 +1,6 @@
-"""tools/summarize_prof.py <gpurun_out/prof_dir> <tag> -- condenses a rocprofv3 run (kernel-trace stats + separate
-FETCH_SIZE / WRITE_SIZE passes, as MI355X_MICROARCH.md's HBM section prescribes) into profiles/<tag>_*."""
+"""tools/summarize_prof.py <gpurun_out/prof_dir> <tag> [workload] -- condenses a rocprofv3 run (kernel-trace stats + separate
+FETCH_SIZE / WRITE_SIZE passes, as MI355X_MICROARCH.md's HBM section prescribes) into profiles/<tag>_*; with a workload key (c2, c3) also refreshes that entry of
+profiles/pmc_traffic.json, the per-SpMV HBM traffic bench.py reports as roofline.traffic."""
 import collections
 import csv
 import glob
@@ -37,7 +38,7 @@ for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         if r["Counter_Name"] == counter:
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        if k.startswith(("void k_", "k_")) or "::k_pb_" in k:
+        if k.startswith(("void k_", "k_")) or "::k_pb" in k:
             pmc.setdefault(k, {})[counter + "_KiB_avg_per_launch"] = sum(v) / len(v)
             pmc[k][counter + "_launches"] = len(v)
 # HBM traffic per launch: FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM section):
@@ -56,4 +57,16 @@ for name in ("bench_kt.json", "bench_fetch.json", "bench_write.json"):
         if lines:
             bench[name] = json.loads(lines[-1])
 json.dump({"pmc": pmc, "bench_lines": bench}, open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1)
-print("wrote", os.listdir(out_dir))
+if len(sys.argv) > 3:
+    spmv = ("k_spmv<", "k_long_finish", "k_pb_scatter", "k_pb_gather", "k_pb_finish")
+    kern = {k[:60]: d["hbm_bytes_per_launch_corrected"] for k, d in pmc.items()
+            if any(s in k for s in spmv) and "hbm_bytes_per_launch_corrected" in d}
+    path = os.path.join(out_dir, "pmc_traffic.json")
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    table[sys.argv[3]] = {
+        "kernels": kern, "hbm_bytes_per_launch": sum(kern.values()),
+        "source": f"profiles/{tag}_pmc.json: sum over the kernels of one SpMV (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                  "separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; the doubling was checked on k_scale / "
+                  "k_axpy_norm, whose byte counts are known)"}
+    json.dump(table, open(path, "w"), indent=1)
+print("wrote", sorted(os.listdir(out_dir)))
