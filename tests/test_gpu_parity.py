@@ -13,9 +13,13 @@ def rel_inf(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
 
-# engine modes: plain gather path (bit-exact body rows), propagation-blocked path, the same with a tiny hub so that
-# almost every entry goes through the blocked passes
-MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=64)]
+# engine modes: plain gather path (bit-exact body rows); propagation-blocked path (long runs cross the two passes as
+# partial row sums); the same with a tiny hub so that almost every entry goes through the blocked passes; every run
+# plain (one x value per entry); a mix of reduced and plain runs with row bands cut into many gather items and small
+# scatter units
+MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=64),
+         dict(propagation_blocking=1, pb_reduce=0),
+         dict(propagation_blocking=1, hub_entries=512, pb_reduce=1500, pb_target=1024, pb_unit=4096)]
 
 
 def graphs(O):
@@ -70,6 +74,9 @@ def test_spmv_matches_oracle(oracle, engine_factory):
             gi = eng.info()
             n_active = int((np.diff(rp.astype(np.int64)) > 0).sum())   # blocked only if some referenced column is not staged
             assert (gi["pb_entries"] > 0) == (n_active > gi["hub_entries"]), (name, mode)
+            assert gi["pb_reduced_entries"] <= gi["pb_entries"], (name, mode)
+            if mode.get("pb_reduce", 1) == 0:      # one value per (padded) entry
+                assert gi["pb_reduced_entries"] == 0 and gi["pb_values"] >= gi["pb_entries"], (name, mode)
             assert np.allclose(eng.spmv(x), y_ref, rtol=1e-13, atol=0), (name, mode)
             eng.close()
         eng = engine_factory(**MODES[0])
@@ -178,11 +185,15 @@ def test_local_group_overlapped_exchange(oracle, pkg):
     x = np.random.default_rng(9).random(n)
     y_ref = O.spmv(rp, ci, x)
     results = []
-    for overlap in (1, 0):
-        grp = pkg.LocalGroup([0, 0, 0], propagation_blocking=1, hub_entries=1024, overlap_exchange=overlap)
+    # (overlap, minimum length of a reduced run): the runs of this graph are ~270 entries long, so the default (384)
+    # leaves them plain and 128 makes them reduced, items of 2048 values cut every row band into several
+    for overlap, min_run in ((1, 384), (0, 384), (1, 128)):
+        grp = pkg.LocalGroup([0, 0, 0], propagation_blocking=1, hub_entries=1024, overlap_exchange=overlap, pb_reduce=min_run,
+                             pb_target=2048 if min_run == 128 else -1)
         grp.set_graph_csr(rp, ci)
         gi = grp.engines[1].info()
         assert gi["pb_entries"] > 0 and 0 < gi["exchange_slice"] <= -(-gi["active_vertices"] // 3 // 64) * 64 + 64
+        assert (gi["pb_reduced_entries"] > gi["pb_entries"] // 2) == (min_run == 128), (overlap, min_run, gi)
         assert np.allclose(grp.spmv(x), y_ref, rtol=1e-13, atol=0)
         a, b, Q, xn, st = grp.lanczos(x0, k)
         check_leading_coefficients(a, b, a_ref, b_ref, ("overlap", overlap))
