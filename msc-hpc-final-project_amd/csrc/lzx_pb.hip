@@ -245,8 +245,8 @@ __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *
 
 // ---- reduced bands: build ------------------------------------------------------------------------------------
 // reduced runs: entry i of the (row band, column band, row, column)-sorted keys -> its place in the step-padded code
-// table: code = column in band | 0x8000 on the last entry of a piece (same row, same 8-entry lane chunk), row in
-// band, and per step its column band and run
+// table: code = column in band | 0x8000 on the last entry of a piece (same row, same step), row in band, and per
+// step its column band and run
 __global__ void k_pbr_place(const u64 *keys, const u32 *runid_incl, const u32 *runstart, const u32 *estart, const uint8_t *fmt,
                             u64 count, uint16_t *rcode, uint16_t *rrow, uint16_t *step_cband, u32 *step_run)
 {
@@ -258,7 +258,7 @@ __global__ void k_pbr_place(const u64 *keys, const u32 *runid_incl, const u32 *r
     const u32 pos = estart[r] + off;
     const u64 k = keys[i];
     const u32 lrow = (u32)((k >> 14) & 0x3ffu);
-    const bool last = (off & (LZX_PBR_CHUNK - 1)) == LZX_PBR_CHUNK - 1 || i + 1 == count || runid_incl[i + 1] - 1 != r ||
+    const bool last = (off & (LZX_PBR_STEP - 1)) == LZX_PBR_STEP - 1 || i + 1 == count || runid_incl[i + 1] - 1 != r ||
                       (u32)((keys[i + 1] >> 14) & 0x3ffu) != lrow;
     rcode[pos] = (uint16_t)((k & 0x3fffu) | (last ? 0x8000u : 0u));
     rrow[pos] = (uint16_t)lrow;
@@ -331,10 +331,13 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 //       entries, pieces written plane by plane, lane-compacted;
 //   plain part: each wavefront walks its own contiguous share of the quads 64 at a time (lane = consecutive quad):
 //       contiguous loads, and 32-byte-per-lane stores that are contiguous inside a run; 4 quads per lane in flight.
+// DBG: the LZX_ABLATE experiment switches behind DESIGN.md's ablation numbers are compiled in (slower even when 0).
+template <bool DBG>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
-             const double *__restrict__ x, u64 xlen, double *val, double *val_plain, int ablate)
+             const double *__restrict__ x, u64 xlen, double *val, double *val_plain, int ablate_arg)
 {
+    const int ablate = DBG ? ablate_arg : 0;
     extern __shared__ __attribute__((aligned(16))) double tile[];   // LZX_PB_CB staged values + a zero for padding
     const u32 band = unit[5 * blockIdx.x];
     const u64 base = (u64)band * LZX_PB_CB;
@@ -351,6 +354,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
         for (u32 j = threadIdx.x; j < LZX_PB_CB; j += 1024) tile[j] = base + j < xlen ? x[base + j] : 0.0;
     }
     if (threadIdx.x < 2) tile[LZX_PB_CB + threadIdx.x] = 0.0;
+    for (u32 j = threadIdx.x; j < 16 * 66; j += 1024) tile[LZX_PB_CB + 2 + j] = 0.0;   // the wavefronts' carry slots
     __syncthreads();
     const u32 lane = threadIdx.x & 63;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -358,21 +362,49 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
 
     {   // ---- reduced bands
         const u32 beg = unit[5 * blockIdx.x + 1], end = unit[5 * blockIdx.x + 2];
+        // A row whose entries span several lanes is summed across them through 65 wave-private LDS slots: every lane
+        // adds what follows its last piece end (its whole sum if it has none) to the slot named after the last lane
+        // before it that holds a piece end; the lane holding the row's end starts its running sum from that slot.
+        // One ds_add + one ds_read per lane and step, no shuffles, no scan.
+        double *carry = tile + LZX_PB_CB + 2 + wv * 66;
         auto body = [&](const uint4 &c, u32 pos) {
             double xv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = tile[pbr_half(c, e) & 0x7fffu];
+            for (int e = 0; e < 8; ++e) xv[e] = ablate == 7 ? (double)pbr_half(c, e) : tile[pbr_half(c, e) & 0x7fffu];
+            u32 ends = 0;   // bit e: entry e closes a piece
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ends |= pbr_flag(c, e) << e;
+            const bool has = ends != 0;
+            const int last = has ? 31 - __clz((int)ends) : -1;
+            double tail = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e > last) tail += xv[e];
+            const unsigned long long holders = __ballot(has);
+            const unsigned long long before = holders & ((1ull << lane) - 1ull);
+            const u32 from = before ? 64u - (u32)__clzll((long long)before) : 0u;   // 1 + last holder before this lane
             double s = 0.0;
+            if (ablate != 8) {
+            atomicAdd(&carry[has ? lane + 1 : from], tail);
+            __builtin_amdgcn_wave_barrier();
+            s = has ? carry[from] : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            if (has) carry[from] = 0.0;
+            }
+            double *out = val + pos;   // wave-uniform: the step's first value slot
+            u32 done = 0;              // pieces of the planes before this one
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bool f = pbr_flag(c, e) != 0;
+                const bool f = (ends >> e) & 1u;
                 s += xv[e];
                 const unsigned long long m = __ballot(f);
-                if (f) {
-                    val[pos + lanes_below(m)] = s;
-                    s = 0.0;
+                if (m) {               // scalar branch: steps of few long rows have mostly empty planes
+                    if (f) {
+                        if (ablate != 6 || s == 1.2345e-300) out[done + lanes_below(m)] = s;
+                        s = 0.0;
+                    }
+                    done += (u32)__popcll(m);
                 }
-                pos += (u32)__popcll(m);
             }
         };
         u32 s = beg + wv;
@@ -382,12 +414,12 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 c[u] = scode[(size_t)(s + u * W) * 64 + lane];
-                b[u] = sbase[s + u * W];
+                b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) body(c[u], b[u]);
         }
-        for (; s < end; s += W) body(scode[(size_t)s * 64 + lane], sbase[s]);
+        for (; s < end; s += W) body(scode[(size_t)s * 64 + lane], (u32)__builtin_amdgcn_readfirstlane((int)sbase[s]));
     }
 
     {   // ---- plain bands
@@ -1020,13 +1052,14 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                   hipEvent_t v_ready)
 {
     if (!c->pb) return LZX_OK;
-    const size_t lds1 = ((size_t)LZX_PB_CB + 2) * sizeof(double);
-    if (c->pb_units)
-        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    const size_t lds1 = ((size_t)LZX_PB_CB + 2 + 16 * 66) * sizeof(double);
     static const int ablate = getenv("LZX_ABLATE") ? atoi(getenv("LZX_ABLATE")) : 0;
+    auto kern = ablate ? k_pb_scatter<true> : k_pb_scatter<false>;
+    if (c->pb_units)
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     auto scatter = [&](u32 u0, u32 u1) {
         if (u1 > u0)
-            hipLaunchKernelGGL(k_pb_scatter, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
+            hipLaunchKernelGGL(kern, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
                                c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val,
                                c->d_pb_val + c->pb_val_offset, ablate);
     };
