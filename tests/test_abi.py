@@ -57,3 +57,23 @@ def test_argument_errors_without_gpu(pkg):
     assert b"null" in L.lzx_last_error()
     assert L.lzx_set_option(None, b"hub_entries", 1) == -1
     assert L.lzx_sync(None) == -1
+
+
+def test_struct_layouts_match_the_header(pkg, tmp_path):
+    """The ctypes mirrors of lzx_stats / lzx_graph_info have the size and field offsets gcc gives the header's."""
+    fields = {"lzx_stats": [f for f, _ in pkg.LzxStats._fields_], "lzx_graph_info": [f for f, _ in pkg.LzxGraphInfo._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "lzx.h"', "int main(void) {"]
+    for s, fs in fields.items():
+        src.append(f'printf("{s} %zu\\n", sizeof({s}));')
+        for f in fs:
+            src.append(f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));')
+    src.append("return 0; }")
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for s, cls in (("lzx_stats", pkg.LzxStats), ("lzx_graph_info", pkg.LzxGraphInfo)):
+        assert int(got[s]) == ctypes.sizeof(cls), s
+        for f, _ in cls._fields_:
+            assert int(got[f"{s}.{f}"]) == getattr(cls, f).offset, (s, f)
