@@ -173,6 +173,9 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  *                           rows are summed in the reference's order and come out bit-identical to serial/
  *   "overlap_exchange"      several ranks: 1 / 0 allow / forbid the two-chunk all-gather that overlaps the blocked
  *                           SpMV (default: allowed)
+ *   "lazy_normalisation"    several ranks: 1 (default) exchange the unnormalised vector so that one 2-double all-reduce
+ *                           per iteration carries alpha and beta; 0 = two 1-double all-reduces, the reference's
+ *                           operation order
  *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "side_stream"
  *                           experiment knobs behind DESIGN.md's tuning log (tools/perf_probe.py)               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);

@@ -105,6 +105,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_reduce")) c->pb_reduce_opt = value;
     else if (!strcmp(name, "pb_unit")) c->pb_unit_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
+    else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
@@ -261,7 +262,74 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     const u32 np = lzx_spmv_partials(c0);
 
     const bool overlap = multi && c0->overlap;
-    for (u32 j = 0; j < k; ++j) {
+    // Several ranks: exchange and multiply the UNNORMALISED vector u_j = beta_{j-1} q_j, so that beta_{j-1}^2 =
+    // ||u_j||^2 travels in the same all-reduce as u_j . (A u_j) (k_lazy_update): one 2-double all-reduce per
+    // iteration instead of two dependent 1-double ones, and the exchange of u_{j+1} starts straight after the vector
+    // kernel instead of after a second reduction.  Same recurrence, operands rounded at slightly different places
+    // (w / beta instead of A (u / beta)); one rank keeps the reference's exact operation order below.
+    const bool lazy = multi && c0->lazy_opt != 0;
+    for (u32 j = 0; lazy && j < k; ++j) {
+        const bool first = j == 0, last = j == k - 1;
+        if (overlap && j > 0) {
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_HIP(hipStreamWaitEvent(c->stream, c->ev_c0, 0));
+            }
+            LZX_TRY(mk.tick(CAT_COMM));
+        }
+        for (lzx_ctx *c : cs) {
+            LZX_HIP(hipSetDevice(c->device));
+            const double *uj = first ? c->d_Q : c->d_u[j & 1];   // u_0 = q_0
+            SpmvLaunch l{c->d_xbuf, uj, c->d_v, c->d_partials};
+            if (overlap && j > 0) l.chunk1_ready = c->ev_c1;
+            LZX_TRY(lzx_launch_spmv(c, l));
+        }
+        LZX_TRY(mk.tick(CAT_SPMV));
+        u32 np2 = 0;
+        for (lzx_ctx *c : cs) {
+            LZX_HIP(hipSetDevice(c->device));
+            // [u_j . w, ||u_j||^2] of this rank (the second from the previous iteration's k_lazy_update)
+            LZX_TRY(lzx_launch_reduce2(c, c->d_partials, lzx_spmv_partials(c), c->d_partials2, first ? 0 : c->np2_last, c->d_scal + 0));
+        }
+        LZX_TRY(lzx_comm_allreduce_sum(cs, 0, 2));
+        LZX_TRY(mk.tick(CAT_COMM));
+        for (lzx_ctx *c : cs) {
+            LZX_HIP(hipSetDevice(c->device));
+            const double *uj = first ? c->d_Q : c->d_u[j & 1];
+            LZX_TRY(lzx_launch_lazy_update(c, c->d_v, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_scal + 0, first ? 1 : 0,
+                                           c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), first ? nullptr : c->d_Q + (size_t)j * c->ldq,
+                                           last ? nullptr : c->d_u[(j + 1) & 1], c->d_partials2, &np2));
+            c->np2_last = np2;
+        }
+        LZX_TRY(mk.tick(CAT_VEC));
+        if (last) break;
+        for (size_t i = 0; i < cs.size(); ++i) {
+            src[i] = cs[i]->d_u[(j + 1) & 1];
+            dst[i] = cs[i]->d_xbuf;
+        }
+        if (!overlap) {
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs));   // only the prefix that has edges
+            LZX_HIP(hipSetDevice(c0->device));
+            LZX_TRY(mk.tick(CAT_COMM));
+        } else {
+            LZX_TRY(lzx_comm_order(cs, /*from main*/ false, /*to exchange*/ true));
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs0, true));
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_HIP(hipEventRecord(c->ev_c0, c->stream2));
+            }
+            for (size_t i = 0; i < cs.size(); ++i) {
+                src[i] = cs[i]->d_u[(j + 1) & 1] + cs[i]->xs0;
+                dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
+            }
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                LZX_HIP(hipEventRecord(c->ev_c1, c->stream2));
+            }
+        }
+    }
+    for (u32 j = 0; !lazy && j < k; ++j) {
         // v = A q_j ; partials of alpha_j
         if (overlap && j > 0) {
             // chunk 0 of q_j (the high-degree end of every slice, where the staged hub entries and nearly all

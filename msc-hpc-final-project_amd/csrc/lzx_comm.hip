@@ -59,12 +59,6 @@ int rccl_load()
             LZX_FAIL(LZX_ERR_COMM, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_)); \
     } while (0)
 
-__global__ void k_sum_ranks(const double *vals, int world, double *out)
-{
-    double s = 0.0;
-    for (int p = 0; p < world; ++p) s += vals[p];  // rank order: fixed
-    *out = s;
-}
 }  // namespace
 
 extern "C" int lzx_comm_unique_id(uint8_t id[128])
@@ -160,26 +154,36 @@ int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream
 // Make every stream in cs wait for everything queued so far on every other stream in cs.
 static int cross_barrier(std::vector<lzx_ctx *> &cs, bool s2 = false) { return lzx_comm_order(cs, s2, s2); }
 
-// d_scal[slot] <- sum over ranks of d_scal[slot], on every handle.
-int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot)
+__global__ void k_sum_ranks_n(const double *vals, int world, u32 count, double *out)
+{
+    for (u32 i = 0; i < count; ++i) {
+        double s = 0.0;
+        for (int p = 0; p < world; ++p) s += vals[(size_t)p * count + i];  // rank order: fixed
+        out[i] = s;
+    }
+}
+
+// d_scal[slot + i] <- sum over ranks of d_scal[slot + i], i < count, on every handle.
+int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count)
 {
     lzx_ctx *c0 = cs[0];
     if (c0->world == 1) return LZX_OK;
     if (c0->comm_kind == 2) {
-        LZX_NCCL(g_rccl.AllReduce(c0->d_scal + slot, c0->d_scal + slot, 1, ncclDouble, ncclSum,
+        LZX_NCCL(g_rccl.AllReduce(c0->d_scal + slot, c0->d_scal + slot, count, ncclDouble, ncclSum,
                                   static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
         return LZX_OK;
     }
-    // local: rank 0 collects, sums in rank order, hands the total back
+    // local: rank 0 collects, sums in rank order, hands the totals back
     const int world = c0->world;
     if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
+    if (slot + count > 8 || (size_t)world * count > 64) LZX_FAIL(LZX_ERR_LIMIT, "local all-reduce: %u values on %d ranks", count, world);
     LZX_TRY(cross_barrier(cs));
     LZX_HIP(hipSetDevice(c0->device));
     for (int p = 0; p < world; ++p)
-        LZX_HIP(hipMemcpyAsync(c0->d_scal + 8 + p, cs[p]->d_scal + slot, sizeof(double), hipMemcpyDefault, c0->stream));
-    hipLaunchKernelGGL(k_sum_ranks, dim3(1), dim3(1), 0, c0->stream, c0->d_scal + 8, world, c0->d_scal + slot);
+        LZX_HIP(hipMemcpyAsync(c0->d_scal + 8 + (size_t)p * count, cs[p]->d_scal + slot, sizeof(double) * count, hipMemcpyDefault, c0->stream));
+    hipLaunchKernelGGL(k_sum_ranks_n, dim3(1), dim3(1), 0, c0->stream, c0->d_scal + 8, world, count, c0->d_scal + slot);
     for (int p = 1; p < world; ++p)
-        LZX_HIP(hipMemcpyAsync(cs[p]->d_scal + slot, c0->d_scal + slot, sizeof(double), hipMemcpyDefault, c0->stream));
+        LZX_HIP(hipMemcpyAsync(cs[p]->d_scal + slot, c0->d_scal + slot, sizeof(double) * count, hipMemcpyDefault, c0->stream));
     LZX_TRY(cross_barrier(cs));
     return LZX_OK;
 }

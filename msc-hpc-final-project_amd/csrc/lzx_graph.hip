@@ -50,6 +50,8 @@ int lzx_graph_release(lzx_ctx *c)
     dev_free(c->d_item_first);
     dev_free(c->d_long_partial);
     dev_free(c->d_v);
+    dev_free(c->d_u[0]);
+    dev_free(c->d_u[1]);
     dev_free(c->d_Q);
     dev_free(c->d_xbuf);
     dev_free(c->d_ybuf);
@@ -474,6 +476,11 @@ int lzx_graph_prepare(lzx_ctx *c)
 
     // ---- 5. vectors ----
     PREP(dev_alloc(&c->d_v, c->ldq));
+    if (world > 1) {
+        PREP(dev_alloc(&c->d_u[0], c->ldq)); PREP(dev_alloc(&c->d_u[1], c->ldq));
+        PREP_HIP(hipMemsetAsync(c->d_u[0], 0, sizeof(double) * c->ldq, st));
+        PREP_HIP(hipMemsetAsync(c->d_u[1], 0, sizeof(double) * c->ldq, st));
+    }
     PREP(dev_alloc(&c->d_xbuf, c->xlen)); PREP(dev_alloc(&c->d_ybuf, c->iolen));
     PREP(dev_alloc(&c->d_io, n));
     PREP_HIP(hipMemsetAsync(c->d_v, 0, sizeof(double) * c->ldq, st));

@@ -115,6 +115,7 @@ struct lzx_ctx {
     u32 pb_units0 = 0;                 // scatter units whose column band lies wholly in chunk 0
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
+    int64_t lazy_opt = -1;             // several ranks: one 2-double all-reduce per iteration (lazy normalisation): -1/1 on, 0 off
     int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
     int64_t pb_unit_opt = -1;          // entries per scatter unit override
     int64_t pb_reduce_opt = -1;        // reduced bands: -1 auto (on), 0 off, > 1: minimum average run length
@@ -167,6 +168,8 @@ struct lzx_ctx {
 
     // vectors and scalars
     double *d_v = nullptr;             // [ldq]
+    u32 np2_last = 0;                  // partials the last k_lazy_update left in d_partials2
+    double *d_u[2] = {nullptr, nullptr};   // [ldq] each, several ranks: the unnormalised Lanczos vector, alternating (lzx_api.hip)
     double *d_Q = nullptr;             // [q_cols][ldq]
     u32 q_cols = 0;
     u32 k_last = 0;                    // valid basis vectors from the last decomposition
@@ -213,6 +216,9 @@ struct SpmvLaunch {
 int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &a);
 u32 lzx_spmv_partials(const lzx_ctx *c);
 int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, int do_sqrt);
+int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, double *out2);
+int lzx_launch_lazy_update(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *scal2, int first,
+                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out);
 // v -= alpha q_j (+ beta_prev q_jm1); alpha = sum(partials_in); writes alpha_out; partial ||v||^2 out.
 int lzx_launch_axpy_norm(lzx_ctx *c, double *v, const double *qj, const double *qjm1,
                          const double *partials_in, u32 np_in, double *alpha_out,
@@ -227,7 +233,7 @@ int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_la
 int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc);
 
 // ---- lzx_comm.hip ----
-int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot);        // d_scal[slot] on every handle
+int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count = 1);   // d_scal[slot .. slot+count) on every handle
 int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t count,
                        bool on_stream2 = false);
 // everything queued so far on every handle's `from` stream happens before what is queued next on every `to` stream

@@ -366,6 +366,71 @@ k_axpy_norm(double *v, const double *__restrict__ qj, const double *__restrict__
     if (threadIdx.x == 0) partials_out[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
+// Several ranks, lazy normalisation (lzx_api.hip): the vector that was exchanged and multiplied is the UNNORMALISED
+// u_j = beta_{j-1} q_j, so one all-reduce carries both D = u_j . (A u_j) and B = ||u_j||^2:
+//   beta_{j-1} = sqrt(B); alpha_j = D / B; q_j = u_j / beta_{j-1}; A q_j = w / beta_{j-1};
+//   u_{j+1} = A q_j - alpha_j q_j - beta_{j-1} q_{j-1}   (serial/lib/lanczos.cc:26-37, same two rounded updates)
+// first: u_0 = q_0 is already normalised (B := 1).  u_next == nullptr on the last iteration (only q_j is still needed).
+__global__ void __launch_bounds__(LZX_VEC_BLOCK)
+k_lazy_update(const double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ q_prev,
+              const double *scal2, int first, double *alpha_out, double *beta_out, double *q_out, double *u_next,
+              double *partials_out, u32 n)
+{
+    __shared__ double sh[4];
+    const double B = first ? 1.0 : scal2[1];
+    const double beta = first ? 1.0 : sqrt(B);
+    const double alpha = first ? scal2[0] : scal2[0] / B;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *alpha_out = alpha;
+        if (beta_out) *beta_out = beta;
+    }
+    double nrm = 0.0;
+    const u32 stride = gridDim.x * LZX_VEC_BLOCK * 2;
+    for (u32 i = (blockIdx.x * LZX_VEC_BLOCK + threadIdx.x) * 2; i < n; i += stride) {
+        double2 q = *reinterpret_cast<const double2 *>(u + i);
+        if (!first) {
+            q.x /= beta;
+            q.y /= beta;
+        }
+        if (q_out) *reinterpret_cast<double2 *>(q_out + i) = q;
+        if (u_next) {
+            double2 t = *reinterpret_cast<const double2 *>(w + i);
+            if (!first) {
+                t.x /= beta;
+                t.y /= beta;
+            }
+            t.x -= alpha * q.x;
+            t.y -= alpha * q.y;
+            if (q_prev) {
+                const double2 p = *reinterpret_cast<const double2 *>(q_prev + i);
+                t.x -= beta * p.x;
+                t.y -= beta * p.y;
+            }
+            *reinterpret_cast<double2 *>(u_next + i) = t;
+            nrm += t.x * t.x;
+            nrm += t.y * t.y;
+        }
+    }
+    nrm = wave_sum(nrm);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = nrm;
+    __syncthreads();
+    if (threadIdx.x == 0) partials_out[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// two fixed-order sums in one launch: out2[0] = sum pa, out2[1] = sum pb
+__global__ void __launch_bounds__(LZX_VEC_BLOCK)
+k_reduce2(const double *pa, u32 na, const double *pb, u32 nb, double *out2)
+{
+    __shared__ double sh[4];
+    const double a = block_sum_fixed_256(pa, na, sh);
+    __syncthreads();
+    const double b = block_sum_fixed_256(pb, nb, sh);
+    if (threadIdx.x == 0) {
+        out2[0] = a;
+        out2[1] = b;
+    }
+}
+
 // serial/lib/lanczos.cc:39-44: beta_j = sqrt(sum v^2); q_{j+1} = v / beta_j (a true division).
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_scale(const double *__restrict__ v, double *q_next, const double *partials_in, u32 np_in,
@@ -509,6 +574,24 @@ int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, i
 {
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, partials, np, out, do_sqrt);
     LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, double *out2)
+{
+    hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, pa, na, pb, nb, out2);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_lazy_update(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *scal2, int first,
+                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out)
+{
+    const u32 g = vec_grid(c);
+    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, u, q_prev, scal2, first, alpha_out,
+                       beta_out, q_out, u_next, partials_out, c->n_loc_pad);
+    LZX_HIP(hipGetLastError());
+    *np_out = g;
     return LZX_OK;
 }
 

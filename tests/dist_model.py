@@ -7,8 +7,10 @@ import torch
 import torch.distributed as dist
 
 
-def run_rank(pkg_partition, row_ptr, col_idx, x0, k, xs0=None):
-    """Returns (alpha, beta, gathered full-length q vectors (k, n) in the caller's order) on every rank."""
+def run_rank(pkg_partition, row_ptr, col_idx, x0, k, xs0=None, lazy=False):
+    """Returns (alpha, beta, gathered full-length q vectors (k, n) in the caller's order) on every rank.
+    lazy: the product's default at N > 1 -- the unnormalised vector is exchanged and ONE 2-double all-reduce per
+    iteration carries u.(A u) and ||u||^2 (csrc/lzx_kernels.hip: k_lazy_update)."""
     P = pkg_partition
     world, rank = dist.get_world_size(), dist.get_rank()
     n = len(row_ptr) - 1
@@ -62,6 +64,31 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k, xs0=None):
     Q = np.zeros((k, n))
     io_pos = np.empty(n, dtype=np.int64)         # result layout: stride L
     io_pos[order] = P.positions(n, world)
+    def allreduce2(a, b):
+        t = torch.tensor([a, b], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t[0].item()), float(t[1].item())
+
+    if lazy:
+        u, own_sq = q.copy(), 0.0                # u_0 = q_0 (already normalised)
+        for j in range(k):
+            w = spmv_local(xfull)                # A u_j on the exchanged, unnormalised u_j
+            D, B = allreduce2(float(w @ u), own_sq)
+            if j == 0:
+                b, alpha[j], qj = 1.0, D, u
+            else:
+                b = np.sqrt(B)
+                beta[j - 1], alpha[j], qj, w = b, D / B, u / b, w / b
+            Q[j] = allgather(qj, L)[io_pos]      # result gather (not part of the iteration's exchange)
+            if j == k - 1:
+                break
+            t = w - alpha[j] * qj
+            if j > 0:
+                t = t - b * q_prev
+            q_prev, u, own_sq = qj, t, float(t @ t)
+            xfull = exchange(u)
+        return alpha, beta[:k - 1], Q, xn
+
     for j in range(k):
         Q[j] = allgather(q, L)[io_pos]           # result gather (not part of the iteration's exchange)
         v = spmv_local(xfull)

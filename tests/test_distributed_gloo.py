@@ -1,6 +1,6 @@
 """CPU, world_size = 2, gloo: the multi-rank exchange pattern (partition by degree rank, padded
-equal-size slices, all-gather of q_{j+1}, two scalar all-reduces per iteration) reproduces the
-single-process result; and the rendezvous plumbing bench.py uses (id broadcast, barrier, max) works."""
+equal-size slices, all-gather of q_{j+1}, two scalar all-reduces per iteration -- or one 2-double all-reduce on the
+unnormalised vector, the product's default) reproduces the single-process result; and the rendezvous plumbing bench.py uses (id broadcast, barrier, max) works."""
 import os
 import socket
 import sys
@@ -47,6 +47,14 @@ def _worker(rank, world, port, out_dir):
     # the same with the exchange cut in two chunks (as the product does on large graphs): identical numbers
     a2, b2, Q2, _ = dist_model.run_rank(P, rp, ci, np.ones(n), k, xs0=128)
     assert np.array_equal(alpha, a2) and np.array_equal(beta, b2) and np.array_equal(Q, Q2)
+    # the product's default at N > 1: one 2-double all-reduce per iteration on the unnormalised vector.  Same
+    # recurrence, operands rounded at different places: equal to rounding at the start of the recurrence, and the
+    # centrality vector (checked by the parent for the saved variant) within the north star's 1e-10
+    a3, b3, Q3, _ = dist_model.run_rank(P, rp, ci, np.ones(n), k, xs0=128, lazy=True)
+    assert abs(a3[0] - alpha[0]) <= 1e-13 * abs(alpha[0]) and abs(b3[0] - beta[0]) <= 1e-13 * abs(beta[0])
+    assert abs(a3[1] - alpha[1]) <= 1e-11 * max(abs(alpha[1]), abs(alpha[0]))
+    assert np.abs(Q3[:3] - Q[:3]).max() <= 1e-12
+    np.savez(os.path.join(out_dir, f"lazy{rank}.npz"), alpha=a3, beta=b3, Q=Q3)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == world
@@ -74,6 +82,11 @@ def test_two_rank_exchange_matches_single_process(oracle, tmp_path):
     assert abs(a[0] - a_ref[0]) <= 1e-12 * abs(a_ref[0]) and abs(b[0] - b_ref[0]) <= 1e-12 * abs(b_ref[0])
     lam, V = O.eigen(a, b)
     ans = O.mult_out(np.ascontiguousarray(Q.T), V, lam, xn)
+    assert np.abs(ans - ans_ref).max() <= 1e-10 * np.abs(ans_ref).max()
+    z = [np.load(str(tmp_path / f"lazy{p}.npz")) for p in range(world)]
+    assert np.array_equal(z[0]["alpha"], z[1]["alpha"]) and np.array_equal(z[0]["beta"], z[1]["beta"]) and np.array_equal(z[0]["Q"], z[1]["Q"])
+    lam, V = O.eigen(z[0]["alpha"], z[0]["beta"])
+    ans = O.mult_out(np.ascontiguousarray(z[0]["Q"].T), V, lam, xn)
     assert np.abs(ans - ans_ref).max() <= 1e-10 * np.abs(ans_ref).max()
 
 

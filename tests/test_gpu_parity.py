@@ -158,7 +158,10 @@ def test_local_group_matches_single(oracle, pkg):
     n, k = len(rp) - 1, 16
     x0 = np.ones(n)
     a_ref, b_ref, Q_ref, xn_ref, ans_ref = pipeline_ref(O, rp, ci, k, x0)
-    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=256)):
+    # the last two: two 1-double all-reduces per iteration in the reference's operation order, instead of the default
+    # single 2-double one on the unnormalised vector
+    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=256),
+                 dict(propagation_blocking=0, lazy_normalisation=0), dict(propagation_blocking=1, hub_entries=256, lazy_normalisation=0)):
         grp = pkg.LocalGroup([0, 0, 0], **mode)
         grp.set_graph_csr(rp, ci)
         x = np.random.default_rng(5).random(n)
@@ -187,9 +190,9 @@ def test_local_group_overlapped_exchange(oracle, pkg):
     results = []
     # (overlap, minimum length of a reduced run): the runs of this graph are ~270 entries long, so the default (384)
     # leaves them plain and 128 makes them reduced, items of 2048 values cut every row band into several
-    for overlap, min_run in ((1, 384), (0, 384), (1, 128)):
+    for overlap, min_run, lazy in ((1, 384, 1), (0, 384, 1), (1, 128, 1), (1, 384, 0)):
         grp = pkg.LocalGroup([0, 0, 0], propagation_blocking=1, hub_entries=1024, overlap_exchange=overlap, pb_reduce=min_run,
-                             pb_target=2048 if min_run == 128 else -1)
+                             pb_target=2048 if min_run == 128 else -1, lazy_normalisation=lazy)
         grp.set_graph_csr(rp, ci)
         gi = grp.engines[1].info()
         assert gi["pb_entries"] > 0 and 0 < gi["exchange_slice"] <= -(-gi["active_vertices"] // 3 // 64) * 64 + 64
