@@ -215,7 +215,7 @@ def main():
                 "partition": "single GPU" if world == 1 else
                              f"rows dealt round-robin by degree rank over {world} GPUs; per iteration 1 RCCL "
                              f"all-gather of {8 * gi['exchange_slice']} B per rank (only the {gi['active_vertices']} "
-                             f"vertices that have an edge are exchanged) + 2 one-double all-reduces",
+                             f"vertices that have an edge are exchanged; the vector travels unnormalised) + 1 two-double all-reduce",
                 "exchange_tuning_ms_per_iter": tune or None,
                 "graph_build_s": round(t_gen, 3),
                 # not `value`: the same K iterations with the host hand-over (x0 upload, basis set-up) and the download
