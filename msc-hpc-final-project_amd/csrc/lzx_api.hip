@@ -292,7 +292,8 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             LZX_TRY(lzx_launch_reduce2(c, c->d_partials, lzx_spmv_partials(c), c->d_partials2, first ? 0 : c->np2_last, c->d_scal + 0));
         }
         LZX_TRY(lzx_comm_allreduce_sum(cs, 0, 2));
-        LZX_TRY(mk.tick(CAT_COMM));
+        // (no timing mark here: every mark is a barrier packet, ~5 us of drained pipeline between dependent kernels;
+        //  the reduction and its all-reduce are billed to the vector work, the exposed part of the all-gather to comm)
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
             const double *uj = first ? c->d_Q : c->d_u[j & 1];
@@ -378,7 +379,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
                                          multi ? 1 : lzx_spmv_partials(c), c->d_alpha + j,
                                          j > 0 ? c->d_beta + (j - 1) : nullptr, c->d_partials2, &np2));
         }
-        LZX_TRY(mk.tick(CAT_VEC));
+        if (multi) LZX_TRY(mk.tick(CAT_VEC));   // one rank: a single mark after k_scale covers both vector kernels
 
         if (multi) {
             for (lzx_ctx *c : cs) {
