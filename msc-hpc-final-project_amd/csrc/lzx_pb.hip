@@ -1064,7 +1064,9 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                                c->d_pb_val + c->pb_val_offset, ablate);
     };
     // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
-    if (chunk1_ready) {
+    if (c->phase_mask_opt & 4) {
+        // experiment: gather pass alone (reads values a previous SpMV left)
+    } else if (chunk1_ready) {
         scatter(0, c->pb_units0);
         LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
         scatter(c->pb_units0, c->pb_units);
@@ -1076,6 +1078,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);
     LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    if (!(c->phase_mask_opt & 8))
     hipLaunchKernelGGL(k_pb_gather, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_lrow,
                        c->d_pb_val, v, q_loc, c->d_pb_part, partials);

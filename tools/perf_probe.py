@@ -56,6 +56,8 @@ if __name__ == "__main__":
         opts = [dict(), dict(pb_target=4096), dict(pb_target=8192), dict(pb_target=32768), dict(pb_reduce=128), dict(pb_reduce=192), dict(pb_reduce=256), dict()]
     if "tgt" in sets:
         opts = [dict(), dict(pb_target=4096), dict(pb_target=6144), dict(pb_target=8192), dict(pb_target=12288), dict(pb_target=2048)]
+    if "iso" in sets:
+        opts = [dict(), dict(phase_mask=3 + 4), dict(phase_mask=3 + 8), dict()]
     if "one" in sets:
         opts = [dict(pb_reduce=0)]
     if "phase" in sets:
