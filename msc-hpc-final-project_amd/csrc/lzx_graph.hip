@@ -391,7 +391,9 @@ int lzx_graph_prepare(lzx_ctx *c)
     }
 
     // ---- 3. host: split rows / slices (local rows are sorted by degree, descending) ----
-    const u32 long_thr = c->long_row_opt > 0 ? (u32)c->long_row_opt : LZX_LONG_ROW;
+    // blocked mode: the tables hold staged columns only and a lane's packets come from LDS-only sums, so wider slices
+    // cost less than more split-row items (C3 staged-column kernel 0.127 -> 0.118 ms from 128 to 256; 512+ loses again)
+    const u32 long_thr = c->long_row_opt > 0 ? (u32)c->long_row_opt : (pb ? 2 * LZX_LONG_ROW : LZX_LONG_ROW);
     u32 n_long = 0;
     for (u32 l = 0; l < c->n_loc_real; ++l)
         if (degl[l] > long_thr) n_long = l + 1;

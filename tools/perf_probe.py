@@ -58,6 +58,8 @@ if __name__ == "__main__":
         opts = [dict(), dict(pb_target=4096), dict(pb_target=6144), dict(pb_target=8192), dict(pb_target=12288), dict(pb_target=2048)]
     if "iso" in sets:
         opts = [dict(), dict(phase_mask=3 + 4), dict(phase_mask=3 + 8), dict()]
+    if "lr" in sets:
+        opts = [dict(), dict(long_row=256), dict(long_row=512), dict(long_row=1024), dict(long_row=2048), dict(long_row=256)]
     if "one" in sets:
         opts = [dict(pb_reduce=0)]
     if "phase" in sets:
