@@ -51,17 +51,15 @@ static constexpr u32 LZX_VEC_BLOCK = 256;
 // Zero tail behind every full-length vector: the padding column index points here.
 static constexpr u32 LZX_TAIL = 64;
 // Propagation blocking (csrc/lzx_pb.hip): column band staged in LDS by the scatter phase (doubles),
-// rows per wavefront-private LDS y tile in the gather phase, entries per scatter work unit.
+// rows per wavefront-private LDS y tile in the gather phase.
 static constexpr u32 LZX_PB_CB = 16384;
 static constexpr u32 LZX_PB_RB = 1024;
-static constexpr u32 LZX_PB_UNIT = 1u << 18;
-static constexpr u32 LZX_PB_TARGET = 32768;   // entries per row band = per gather wavefront
+static constexpr u32 LZX_PB_TARGET = 32768;   // upper limit of the values per gather item (one wavefront each)
 static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
-// reduced bands (partial row sums instead of single values cross the two passes)
-static constexpr u32 LZX_PBR_CHUNK = 8;       // consecutive entries one lane adds up (one 16-byte load)
-static constexpr u32 LZX_PBR_STEP = 512;      // entries per wavefront step; runs of reduced bands are padded to whole steps
-static constexpr u32 LZX_PBR_MIN_RUN = 384;   // a band is reduced when its (row band, column band) runs average this many entries
+// reduced runs (partial row sums instead of single values cross the two passes)
+static constexpr u32 LZX_PBR_STEP = 512;      // entries per wavefront step; reduced runs are padded to whole steps
+static constexpr u32 LZX_PBR_MIN_RUN = 384;   // a (row band, column band) run of at least this many entries is reduced
 
 struct lzx_ctx {
     int device = 0;
@@ -160,8 +158,7 @@ struct lzx_ctx {
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;
     u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)
-    u64 pbr_entries = 0;               // entries of the reduced bands
-    u64 pb_val_offset = 0;             // first value of the plain bands in d_pb_val (the reduced bands' pieces come first)
+    u64 pbr_entries = 0;               // entries of the reduced runs
     uint4 *d_pbr_code = nullptr;       // [pbr_steps][64] scatter order: 8 x (column in band | piece-end flag) per lane
     u32 *d_pbr_base = nullptr;         // [pbr_steps] first value slot of the step
     u32 pbr_steps = 0;

@@ -2,31 +2,34 @@
 //
 // Why: past the 4 MiB per-XCD L2 a random 8-byte gather of x costs a whole 128-byte fabric transaction
 // (tools/gather_bench.hip: 55 Ggather/s = 7 TB/s of traffic), and even L2-resident gathers top out near
-// 200 Ggather/s, so the plain CSR gather moves 8x the algorithmic bytes (profiles/r1_c3_pmc.json: 15 GB per SpMV
-// on the 10 M-vertex graph).  Here the same work is two streaming passes around LDS:
-//   scatter (k_pb_scatter): entries ordered by COLUMN band; the band's 16 Ki x values are staged in LDS; a lane
-//       takes a QUAD of four entries (one 8-byte load of their columns-in-band, one 4-byte load of the quad's
-//       slot), looks the four values up in LDS and writes them with two 16-byte stores.  Slots are ordered by ROW
-//       band, so a (row band, column band) run is one contiguous stretch of writes; runs are padded to whole quads
-//       (padding reads a zero kept behind the staged band).
-//   gather (k_pb_gather): row bands hold about LZX_PB_TARGET entries each (1 .. 1024 consecutive rows, so heavy
-//       rows get bands of their own and every wavefront gets the same amount of work); one wavefront streams a
-//       band's values + 2-byte LDS slot and adds each value into a wave-private LDS y tile with ds_add_f64.  The
-//       slot of an entry is row * rep + replica, the replica chosen when the graph is reshaped so that the 64
-//       lanes of one step (almost) never share a slot: no shuffles, no serialised conflicts; only this wavefront
-//       touches the tile, so additions happen in program order.  The tile is then folded (rep replicas per row),
-//       added to v, and the wave forms its share of alpha = v . q.  A single row with more than 2 targets of
-//       entries is cut into items whose totals k_pb_finish adds in order.
-//   reduced part of the scatter pass: the first row bands -- the high-degree rows, where a row has many entries in
-//       one column band (on the 10 M-vertex R-MAT graph the 222 M blocked entries of rows with degree >= 128 form
-//       only 37 M distinct (row, column band) pairs) -- do not pass single x values to the gather pass but partial
-//       row sums.  Their (row band, column band) runs are cut into steps of 512 entries; lane l of a wavefront takes
-//       8 consecutive entries (one 16-byte load of 15-bit columns-in-band, bit 15 = "last entry of its row in this
-//       lane"), adds them up from LDS and emits one value per piece.  Pieces that close at entry e of their lane form
-//       plane e of the step and are written lane-compacted (ballot + mbcnt), so every store instruction writes one
-//       contiguous stretch and no prefix scan is needed; the matching row slots are static.  Several pieces of one
-//       row are simply added by the gather pass, like single entries are.
-// All tables are static (built once per graph by lzx_pb_prepare: radix sorts and a few scans).
+// 200 Ggather/s, so the plain CSR gather moves 8x the algorithmic bytes (profiles/r1_c3_baseline_pmc.json: 15 GB per
+// SpMV on the 10 M-vertex graph).  Here the same work is two streaming passes around LDS.
+//
+// Bands and runs.  Column bands = 16 Ki positions of the exchange layout (one 128 KiB LDS tile of x).  Row bands =
+// consecutive local rows, 1024 of them (fewer at the top of the degree order, see pb_prepare_impl).  The entries of one
+// (row band, column band) pair are a RUN; the gather order of everything is (row band, column band, row, column).
+//
+//   scatter (k_pb_scatter): work ordered by COLUMN band; a workgroup stages the band's x values in LDS once and walks
+//     REDUCED runs (>= LZX_PBR_MIN_RUN entries: the runs of the high-degree rows and, in every row band, those of the
+//       popular columns -- a row has many entries per column band there, so PARTIAL ROW SUMS cross the passes, not
+//       x values): cut into steps of 512 entries; lane l of a wavefront takes 8 consecutive entries (one 16-byte
+//       load of 15-bit columns-in-band, bit 15 = last entry of a PIECE = of its row within the step), adds them up
+//       from LDS, rows that span lanes being summed through wave-private LDS carry slots, and emits one value per
+//       piece.  Pieces that close at entry e of their lane form plane e of the step and are written lane-compacted
+//       (ballot + mbcnt): every store instruction writes one contiguous stretch, no prefix scan, and the matching
+//       row slots are static.  Several pieces of one row are simply added by the gather pass.
+//     PLAIN runs (shorter): padded to 8 entries; a lane takes a QUAD of four entries (one 8-byte load of their
+//       columns-in-band, one 4-byte load of the quad's value slot), looks the four values up and writes them with
+//       two 16-byte stores (padding reads a zero kept behind the staged band).
+//     Value slots are in gather order, so a run is one contiguous, 64-byte aligned stretch of writes.
+//   gather (k_pb_gather): a row band's values are cut into items of ~16 Ki values; one wavefront streams an item's
+//     values + 2-byte LDS slots and adds each value into a wave-private LDS y tile with ds_add_f64.  The slot of a
+//     value is row * rep + replica, the replica chosen when the graph is reshaped so that the 64 lanes of one step
+//     (almost) never share a slot: no shuffles, no serialised conflicts; only this wavefront touches the tile, so
+//     additions happen in program order.  The tile is then folded (rep replicas per row) and added to v (the band's
+//     only item) or left as per-row totals that k_pb_finish adds in item order; the wave forms its share of
+//     alpha = v . q.
+// All tables are static (built once per graph by lzx_pb_prepare: radix sorts and a few scans, on the device).
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 template <bool DBG>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
-             const double *__restrict__ x, u64 xlen, double *val, double *val_plain, int ablate_arg)
+             const double *__restrict__ x, u64 xlen, double *val, int ablate_arg)
 {
     const int ablate = DBG ? ablate_arg : 0;
     extern __shared__ __attribute__((aligned(16))) double tile[];   // LZX_PB_CB staged values + a zero for padding
@@ -446,9 +449,9 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
                     hi.y = tile[c[u].y >> 16];
                 }
                 if (ablate == 2) { lo.x = c[u].x; lo.y = c[u].y; hi = lo; }
-                double2 *out = reinterpret_cast<double2 *>(val_plain + d[u]);   // 32-byte aligned: slots of a quad
+                double2 *out = reinterpret_cast<double2 *>(val + d[u]);   // 32-byte aligned: slots of a quad
                 if (ablate == 1) { if (lo.x + lo.y + hi.x + hi.y == 1.2345e-300) out[0] = lo; continue; }
-                if (ablate == 4) out = reinterpret_cast<double2 *>(val_plain + (size_t)(j + u * 64) * 4);
+                if (ablate == 4) out = reinterpret_cast<double2 *>(val + (size_t)(j + u * 64) * 4);
                 out[0] = lo;
                 if (ablate != 3) out[1] = hi;
             }
@@ -460,7 +463,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
             lo.y = tile[c.x >> 16];
             hi.x = tile[c.y & 0xffffu];
             hi.y = tile[c.y >> 16];
-            double2 *out = reinterpret_cast<double2 *>(val_plain + q_dst[j]);
+            double2 *out = reinterpret_cast<double2 *>(val + q_dst[j]);
             out[0] = lo;
             out[1] = hi;
         }
@@ -612,7 +615,7 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pbr_code);
     pb_free(c->d_pbr_base);
     c->pb = false;
-    c->pb_entries = c->pb_values = c->pbr_entries = c->pb_val_offset = 0;
+    c->pb_entries = c->pb_values = c->pbr_entries = 0;
     c->pb_units = c->pb_units0 = c->pb_nr = c->pb_gather_grid = c->pb_n_items = c->pb_n_multi = c->pb_finish_grid = 0;
     c->pbr_steps = 0;
 }
@@ -1027,7 +1030,6 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     c->pb_entries = total;
     c->pbr_entries = red_entries;
     c->pb_values = len;
-    c->pb_val_offset = 0;
     c->pb_nr = nr;
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2, std::max(1u, (c->pb_n_items + waves_per_wg - 1) / waves_per_wg));
@@ -1060,8 +1062,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     auto scatter = [&](u32 u0, u32 u1) {
         if (u1 > u0)
             hipLaunchKernelGGL(kern, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
-                               c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val,
-                               c->d_pb_val + c->pb_val_offset, ablate);
+                               c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val, ablate);
     };
     // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
     if (c->phase_mask_opt & 4) {
