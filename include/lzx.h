@@ -173,9 +173,10 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  *                           rows are summed in the reference's order and come out bit-identical to serial/
  *   "overlap_exchange"      several ranks: 1 / 0 allow / forbid the two-chunk all-gather that overlaps the blocked
  *                           SpMV (default: allowed)
- *   "lazy_normalisation"    several ranks: 1 (default) exchange the unnormalised vector so that one 2-double all-reduce
- *                           per iteration carries alpha and beta; 0 = two 1-double all-reduces, the reference's
- *                           operation order
+ *   "lazy_normalisation"    1: multiply (and, with several ranks, exchange) the unnormalised vector, so that alpha and
+ *                           beta come out of one reduction per iteration (one 2-double all-reduce) and one vector kernel;
+ *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on
+ *                           one GPU in plain mode
  *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "side_stream"
  *                           experiment knobs behind DESIGN.md's tuning log (tools/perf_probe.py)               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);

@@ -267,7 +267,9 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     // iteration instead of two dependent 1-double ones, and the exchange of u_{j+1} starts straight after the vector
     // kernel instead of after a second reduction.  Same recurrence, operands rounded at slightly different places
     // (w / beta instead of A (u / beta)); one rank keeps the reference's exact operation order below.
-    const bool lazy = multi && c0->lazy_opt != 0;
+    // One rank in blocked mode (whose sums are already ordered differently from the reference's) takes the same form:
+    // it saves k_scale's pass over v and a launch; in plain mode one rank keeps the reference's order bit for bit.
+    const bool lazy = c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (multi || c0->codes16));
     for (u32 j = 0; lazy && j < k; ++j) {
         const bool first = j == 0, last = j == k - 1;
         if (overlap && j > 0) {
@@ -280,30 +282,45 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
             const double *uj = first ? c->d_Q : c->d_u[j & 1];   // u_0 = q_0
-            SpmvLaunch l{c->d_xbuf, uj, c->d_v, c->d_partials};
+            SpmvLaunch l{multi ? c->d_xbuf : uj, uj, c->d_v, c->d_partials};
             if (overlap && j > 0) l.chunk1_ready = c->ev_c1;
             LZX_TRY(lzx_launch_spmv(c, l));
         }
         LZX_TRY(mk.tick(CAT_SPMV));
         u32 np2 = 0;
-        for (lzx_ctx *c : cs) {
-            LZX_HIP(hipSetDevice(c->device));
-            // [u_j . w, ||u_j||^2] of this rank (the second from the previous iteration's k_lazy_update)
-            LZX_TRY(lzx_launch_reduce2(c, c->d_partials, lzx_spmv_partials(c), c->d_partials2, first ? 0 : c->np2_last, c->d_scal + 0));
+        if (multi) {
+            for (lzx_ctx *c : cs) {
+                LZX_HIP(hipSetDevice(c->device));
+                // [u_j . w, ||u_j||^2] of this rank (the second from the previous iteration's k_lazy_update)
+                LZX_TRY(lzx_launch_reduce2(c, c->d_partials, lzx_spmv_partials(c), c->d_partials2, first ? 0 : c->np2_last, c->d_scal + 0));
+            }
+            LZX_TRY(lzx_comm_allreduce_sum(cs, 0, 2));
         }
-        LZX_TRY(lzx_comm_allreduce_sum(cs, 0, 2));
         // (no timing mark here: every mark is a barrier packet, ~5 us of drained pipeline between dependent kernels;
         //  the reduction and its all-reduce are billed to the vector work, the exposed part of the all-gather to comm)
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
             const double *uj = first ? c->d_Q : c->d_u[j & 1];
+            // one rank: both sums are closed in the kernel's prologue from the partials themselves (no reduce launch);
+            // the norm partials alternate between two arrays, the kernel reads one while writing the other
+            double *p_out = multi ? c->d_partials2 : ((j & 1) ? c->d_partials3 : c->d_partials2);
+            const double *p_in = multi ? nullptr : ((j & 1) ? c->d_partials2 : c->d_partials3);
+            if (!multi)
+                LZX_TRY(lzx_launch_lazy_update_local(c, c->d_v, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_partials,
+                                                     lzx_spmv_partials(c), p_in, first ? 0 : c->np2_last, first ? 1 : 0, c->d_alpha + j,
+                                                     first ? nullptr : c->d_beta + (j - 1), first ? nullptr : c->d_Q + (size_t)j * c->ldq,
+                                                     last ? nullptr : c->d_u[(j + 1) & 1], p_out, &np2));
+            else
             LZX_TRY(lzx_launch_lazy_update(c, c->d_v, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_scal + 0, first ? 1 : 0,
                                            c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), first ? nullptr : c->d_Q + (size_t)j * c->ldq,
                                            last ? nullptr : c->d_u[(j + 1) & 1], c->d_partials2, &np2));
             c->np2_last = np2;
         }
         LZX_TRY(mk.tick(CAT_VEC));
-        if (last) break;
+        if (last || !multi) {
+            if (last) break;
+            continue;
+        }
         for (size_t i = 0; i < cs.size(); ++i) {
             src[i] = cs[i]->d_u[(j + 1) & 1];
             dst[i] = cs[i]->d_xbuf;

@@ -58,6 +58,7 @@ int lzx_graph_release(lzx_ctx *c)
     dev_free(c->d_io);
     dev_free(c->d_partials);
     dev_free(c->d_partials2);
+    dev_free(c->d_partials3);
     lzx_pb_release(c);
     c->q_cols = 0;
     c->k_last = 0;
@@ -478,7 +479,7 @@ int lzx_graph_prepare(lzx_ctx *c)
 
     // ---- 5. vectors ----
     PREP(dev_alloc(&c->d_v, c->ldq));
-    if (world > 1) {
+    {
         PREP(dev_alloc(&c->d_u[0], c->ldq)); PREP(dev_alloc(&c->d_u[1], c->ldq));
         PREP_HIP(hipMemsetAsync(c->d_u[0], 0, sizeof(double) * c->ldq, st));
         PREP_HIP(hipMemsetAsync(c->d_u[1], 0, sizeof(double) * c->ldq, st));
@@ -503,7 +504,7 @@ int lzx_graph_prepare(lzx_ctx *c)
     c->spmv_grid = grid;
     c->fin_grid = (c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
     c->np_cap = std::max<u32>(c->spmv_grid + c->fin_grid + lzx_pb_partials(c), (u32)c->cu_count * 8) + 8;
-    PREP(dev_alloc(&c->d_partials, c->np_cap)); PREP(dev_alloc(&c->d_partials2, c->np_cap));
+    PREP(dev_alloc(&c->d_partials, c->np_cap)); PREP(dev_alloc(&c->d_partials2, c->np_cap)); PREP(dev_alloc(&c->d_partials3, c->np_cap));
 
     PREP_HIP(hipStreamSynchronize(st));
     cleanup();

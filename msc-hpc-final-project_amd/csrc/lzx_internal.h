@@ -113,7 +113,7 @@ struct lzx_ctx {
     u32 pb_units0 = 0;                 // scatter units whose column band lies wholly in chunk 0
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
-    int64_t lazy_opt = -1;             // several ranks: one 2-double all-reduce per iteration (lazy normalisation): -1/1 on, 0 off
+    int64_t lazy_opt = -1;             // lazy normalisation (lzx_api.hip): -1 = with several ranks and in blocked mode, 0 off, 1 on
     int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
     int64_t pb_unit_opt = -1;          // entries per scatter unit override
     int64_t pb_reduce_opt = -1;        // reduced bands: -1 auto (on), 0 off, > 1: minimum average run length
@@ -176,6 +176,7 @@ struct lzx_ctx {
     double *d_io = nullptr;            // [n] staging in the caller's order
     double *d_partials = nullptr;      // [np_cap] block partials of the running reduction
     double *d_partials2 = nullptr;     // [np_cap]
+    double *d_partials3 = nullptr;     // [np_cap] one rank, lazy normalisation: norm partials alternate with d_partials2
     u32 np_cap = 0;
     double *d_alpha = nullptr, *d_beta = nullptr;  // [k_cap]
     u32 k_cap = 0;
@@ -216,6 +217,9 @@ int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, i
 int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, double *out2);
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out);
+int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *pa, u32 na,
+                                 const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
+                                 double *u_next, double *partials_out, u32 *np_out);
 // v -= alpha q_j (+ beta_prev q_jm1); alpha = sum(partials_in); writes alpha_out; partial ||v||^2 out.
 int lzx_launch_axpy_norm(lzx_ctx *c, double *v, const double *qj, const double *qjm1,
                          const double *partials_in, u32 np_in, double *alpha_out,

@@ -371,15 +371,24 @@ k_axpy_norm(double *v, const double *__restrict__ qj, const double *__restrict__
 //   beta_{j-1} = sqrt(B); alpha_j = D / B; q_j = u_j / beta_{j-1}; A q_j = w / beta_{j-1};
 //   u_{j+1} = A q_j - alpha_j q_j - beta_{j-1} q_{j-1}   (serial/lib/lanczos.cc:26-37, same two rounded updates)
 // first: u_0 = q_0 is already normalised (B := 1).  u_next == nullptr on the last iteration (only q_j is still needed).
+// scal2 == nullptr (one rank): D and B are the fixed-order sums of pa[0..na) and pb[0..nb), closed here by every workgroup.
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_lazy_update(const double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ q_prev,
-              const double *scal2, int first, double *alpha_out, double *beta_out, double *q_out, double *u_next,
-              double *partials_out, u32 n)
+              const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
+              double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n)
 {
     __shared__ double sh[4];
-    const double B = first ? 1.0 : scal2[1];
+    double D, B;
+    if (scal2) {
+        D = scal2[0];
+        B = scal2[1];
+    } else {
+        D = block_sum_fixed_256(pa, na, sh);
+        B = first ? 1.0 : block_sum_fixed_256(pb, nb, sh);
+    }
+    if (first) B = 1.0;
     const double beta = first ? 1.0 : sqrt(B);
-    const double alpha = first ? scal2[0] : scal2[0] / B;
+    const double alpha = first ? D : D / B;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *alpha_out = alpha;
         if (beta_out) *beta_out = beta;
@@ -588,8 +597,20 @@ int lzx_launch_lazy_update(lzx_ctx *c, const double *w, const double *u, const d
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out)
 {
     const u32 g = vec_grid(c);
-    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, u, q_prev, scal2, first, alpha_out,
-                       beta_out, q_out, u_next, partials_out, c->n_loc_pad);
+    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
+                       first, alpha_out, beta_out, q_out, u_next, partials_out, c->n_loc_pad);
+    LZX_HIP(hipGetLastError());
+    *np_out = g;
+    return LZX_OK;
+}
+
+int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *pa, u32 na,
+                                 const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
+                                 double *u_next, double *partials_out, u32 *np_out)
+{
+    const u32 g = vec_grid(c);
+    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, u, q_prev, nullptr, pa, na, pb, nb, first,
+                       alpha_out, beta_out, q_out, u_next, partials_out, c->n_loc_pad);
     LZX_HIP(hipGetLastError());
     *np_out = g;
     return LZX_OK;
