@@ -155,6 +155,7 @@ struct lzx_ctx {
     u32 *d_pb_items = nullptr;         // [pb_n_items][4] row band, begin, end (gather order), slot or ~0
     u32 *d_pb_multi = nullptr;         // [pb_n_multi][4] row, first slot, items, slot stride: rows of bands cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows
+    uint8_t *d_pb_long_multi = nullptr; // [n_long64] 1: the split row is also listed in d_pb_multi
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;
     u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)

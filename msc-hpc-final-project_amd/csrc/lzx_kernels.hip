@@ -58,6 +58,7 @@ struct SpmvArgs {
     u32 hub_real;  // slots that carry x values
     u32 world;
     u32 xs0;       // slice stride of chunk 0 of the exchange layout (the staged hub entries all live there)
+    u32 n_zero;    // blocked mode: v[0 .. n_zero) (the split rows) starts at 0; the blocked passes and k_pb_finish add to it
 };
 
 // Column code c: c < hub -> value staged in LDS slot c; otherwise x[c - hub].
@@ -134,6 +135,8 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
         }
         __syncthreads();
     }
+
+    for (u32 i = blockIdx.x * LZX_SPMV_BLOCK + tid; i < a.n_zero; i += gridDim.x * LZX_SPMV_BLOCK) a.v[i] = 0.0;
 
     const u32 waves = gridDim.x * (LZX_SPMV_BLOCK / 64);
     const u32 w0 = blockIdx.x * (LZX_SPMV_BLOCK / 64) + wv;   // scalar: wv came through readfirstlane
@@ -508,7 +511,7 @@ static u32 vec_grid(const lzx_ctx *c)
     return need < 1 ? 1 : (need < cap ? need : cap);
 }
 
-u32 lzx_spmv_partials(const lzx_ctx *c) { return c->spmv_grid + c->fin_grid + lzx_pb_partials(c); }
+u32 lzx_spmv_partials(const lzx_ctx *c) { return c->spmv_grid + (c->pb ? 0 : c->fin_grid) + lzx_pb_partials(c); }
 
 template <int HUB, bool NT>
 static int launch_spmv_t(lzx_ctx *c, const SpmvArgs &a, hipStream_t st)
@@ -541,6 +544,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.hub_real = c->hub_real;
     a.world = (u32)c->world;
     a.xs0 = c->xs0;
+    a.n_zero = c->pb ? c->n_long64 : 0;
     const bool nt = c->nt_opt > 0;
     // Blocked mode, option "side_stream": the staged-columns kernel and the scatter passes are independent (both only
     // read x), so the former can run on a side stream, its drain overlapping the scatter's ramp-up; the gather pass,
@@ -565,7 +569,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
         else    LZX_TRY((launch_spmv_t<0, false>(c, a, hs)));
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[1], c->stream));
-    if (c->fin_grid > 0) {
+    if (c->fin_grid > 0 && !c->pb) {   // blocked mode: k_pb_finish adds the split rows' totals
         hipLaunchKernelGGL(k_long_finish, dim3(c->fin_grid), dim3(LZX_VEC_BLOCK), 0, hs,
                            c->d_item_first, c->d_long_partial, c->n_long64, l.q_loc, l.v,
                            l.partials + c->spmv_grid);
@@ -574,7 +578,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[2], c->stream));
     // entries whose column is not staged in LDS: two streaming passes that add into v (lzx_pb.hip)
     if (side) LZX_HIP(hipEventRecord(c->ev_join, c->stream3));
-    LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, l.partials + c->spmv_grid + c->fin_grid, l.chunk1_ready, side ? c->ev_join : nullptr));
+    LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, l.partials + c->spmv_grid + (c->pb ? 0 : c->fin_grid), l.chunk1_ready, side ? c->ev_join : nullptr));
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[4], c->stream));
     return LZX_OK;
 }

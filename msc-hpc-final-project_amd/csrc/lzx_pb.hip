@@ -563,9 +563,12 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     }
 }
 
-// rows of bands cut into several items: v[row] += item totals in item order; alpha partials for those rows
+// v[row] += totals that were left for it, in their fixed order; alpha partials for those rows.  Threads [0, n_multi):
+// rows of bands cut into several gather items (their per-item totals); threads behind them: the split rows of the
+// staged-column kernel (their item totals, k_long_finish's job in plain mode).
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
-k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32 n_multi, const double *part, double *v,
+k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32 n_multi, const double *part,
+            const u32 *item_first, const double *long_partial, const uint8_t *long_is_multi, u32 n_long, double *v,
             const double *q_loc, double *partials)
 {
     __shared__ double sh[4];
@@ -576,8 +579,16 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
         const u32 row = m.x;
         double s = 0.0;
         for (u32 k = 0; k < m.z; ++k) s += part[m.y + (size_t)k * m.w];
+        if (row < n_long)   // a split row of a multi-item band: one thread owns the row's update
+            for (u32 it = item_first[row]; it < item_first[row + 1]; ++it) s += long_partial[it];
         v[row] += s;
         dot = s * q_loc[row];
+    } else if (t - n_multi < n_long && !long_is_multi[t - n_multi]) {
+        const u32 r = t - n_multi;
+        double s = 0.0;
+        for (u32 it = item_first[r]; it < item_first[r + 1]; ++it) s += long_partial[it];
+        v[r] += s;
+        dot = s * q_loc[r];
     }
     dot = wave_sum_pb(dot);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
@@ -612,6 +623,7 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_items);
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
+    pb_free(c->d_pb_long_multi);
     pb_free(c->d_pbr_code);
     pb_free(c->d_pbr_base);
     c->pb = false;
@@ -1015,6 +1027,14 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     }
     c->pb_n_items = (u32)(items.size() / 4);
     c->pb_n_multi = (u32)(multi.size() / 4);
+    {   // split rows (the first n_long64 local rows) that are also rows of a multi-item band
+        std::vector<uint8_t> flag((size_t)c->n_long64 + 1, 0);
+        for (size_t i = 0; i < multi.size(); i += 4)
+            if (multi[i] < c->n_long64) flag[multi[i]] = 1;
+        LZX_TRY(pb_alloc(&c->d_pb_long_multi, flag.size()));
+        LZX_HIP(hipMemcpyAsync(c->d_pb_long_multi, flag.data(), flag.size(), hipMemcpyHostToDevice, st));
+        LZX_HIP(hipStreamSynchronize(st));
+    }
     LZX_TRY(pb_alloc(&c->d_pb_items, items.size())); LZX_TRY(pb_alloc(&c->d_pb_multi, multi.size())); LZX_TRY(pb_alloc(&c->d_pb_part, slots));
     if (!items.empty())
         LZX_HIP(hipMemcpyAsync(c->d_pb_items, items.data(), sizeof(u32) * items.size(), hipMemcpyHostToDevice, st));
@@ -1033,7 +1053,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     c->pb_nr = nr;
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2, std::max(1u, (c->pb_n_items + waves_per_wg - 1) / waves_per_wg));
-    c->pb_finish_grid = (c->pb_n_multi + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
+    c->pb_finish_grid = (c->pb_n_multi + c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;   // + the split rows of k_spmv
     return LZX_OK;
 }
 #undef GRID
@@ -1085,8 +1105,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                        c->d_pb_val, v, q_loc, c->d_pb_part, partials);
     if (c->pb_finish_grid)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
-                           reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, v, q_loc,
-                           partials + c->pb_gather_grid);
+                           reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, c->d_item_first,
+                           c->d_long_partial, c->d_pb_long_multi, c->n_long64, v, q_loc, partials + c->pb_gather_grid);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }
