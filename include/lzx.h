@@ -177,7 +177,7 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  *                           beta come out of one reduction per iteration (one 2-double all-reduce) and one vector kernel;
  *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on
  *                           one GPU in plain mode
- *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "side_stream"
+ *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "pb_column_band", "side_stream"
  *                           experiment knobs behind DESIGN.md's tuning log (tools/perf_probe.py)               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ u64 pack_key(u32 rband, u32 cband, u32 lrow, u32 lcol
 // one wavefront (64-thread block) per local row: keep the entries whose code is not a hub slot
 __global__ void __launch_bounds__(64)
 k_pb_emit(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, const u32 *old_of_local,
-          const u32 *deg_local, const u32 *nh_off, u32 hub, const u32 *band_row0, u32 nr, u64 *keys)
+          const u32 *deg_local, const u32 *nh_off, u32 hub, const u32 *band_row0, u32 nr, u32 cb, u64 *keys)
 {
     const u32 l = blockIdx.x, lane = threadIdx.x;
     const u32 d = deg_local[l];
@@ -73,7 +73,7 @@ k_pb_emit(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, const 
         if (keep) {
             const u32 p = cde - hub;
             const u32 pre = __popcll(m & ((1ull << lane) - 1ull));
-            keys[out + pre] = pack_key(R, p / LZX_PB_CB, lrow, p % LZX_PB_CB);
+            keys[out + pre] = pack_key(R, p / cb, lrow, p % cb);
         }
         out += __popcll(m);
     }
@@ -329,35 +329,36 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 
 // ---- the per-iteration kernels --------------------------------------------------------------------------------
 // Scatter pass.  unit = {column band, first step, last step, first quad, last quad}: the workgroup stages the band's
-// LZX_PB_CB x values (plus a zero for padding) in LDS once and then walks its share of both tables.
+// CB x values (plus a zero for padding) in LDS once and then walks its share of both tables.  CB = 16 Ki (128 KiB, one
+// workgroup per CU) or, for graphs whose x sits in the L2s, 8 Ki (two workgroups per CU).
 //   reduced part: wavefront w takes steps w, w+16, ... of the unit, four steps' loads in flight; lane = 8 consecutive
 //       entries, pieces written plane by plane, lane-compacted;
 //   plain part: each wavefront walks its own contiguous share of the quads 64 at a time (lane = consecutive quad):
 //       contiguous loads, and 32-byte-per-lane stores that are contiguous inside a run; 4 quads per lane in flight.
 // DBG: the LZX_ABLATE experiment switches behind DESIGN.md's ablation numbers are compiled in (slower even when 0).
-template <bool DBG>
+template <u32 CB, bool DBG>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
              const double *__restrict__ x, u64 xlen, double *val, int ablate_arg)
 {
     const int ablate = DBG ? ablate_arg : 0;
-    extern __shared__ __attribute__((aligned(16))) double tile[];   // LZX_PB_CB staged values + a zero for padding
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // CB staged values + a zero for padding
     const u32 band = unit[5 * blockIdx.x];
-    const u64 base = (u64)band * LZX_PB_CB;
+    const u64 base = (u64)band * CB;
     // staging is dead time for this CU (the tile leaves room for one workgroup): all eight 16-byte loads of a
     // thread are issued before the first LDS write, so it costs one memory round trip
-    if (base + LZX_PB_CB <= xlen) {
+    if (base + CB <= xlen) {
         const double2 *src = reinterpret_cast<const double2 *>(x + base);   // band starts are 128 KiB aligned
-        double2 t[LZX_PB_CB / 2048];
+        double2 t[CB / 2048];
 #pragma unroll
-        for (u32 u = 0; u < LZX_PB_CB / 2048; ++u) t[u] = src[threadIdx.x + u * 1024];
+        for (u32 u = 0; u < CB / 2048; ++u) t[u] = src[threadIdx.x + u * 1024];
 #pragma unroll
-        for (u32 u = 0; u < LZX_PB_CB / 2048; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = t[u];
+        for (u32 u = 0; u < CB / 2048; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = t[u];
     } else {
-        for (u32 j = threadIdx.x; j < LZX_PB_CB; j += 1024) tile[j] = base + j < xlen ? x[base + j] : 0.0;
+        for (u32 j = threadIdx.x; j < CB; j += 1024) tile[j] = base + j < xlen ? x[base + j] : 0.0;
     }
-    if (threadIdx.x < 2) tile[LZX_PB_CB + threadIdx.x] = 0.0;
-    for (u32 j = threadIdx.x; j < 16 * 66; j += 1024) tile[LZX_PB_CB + 2 + j] = 0.0;   // the wavefronts' carry slots
+    if (threadIdx.x < 2) tile[CB + threadIdx.x] = 0.0;
+    for (u32 j = threadIdx.x; j < 16 * 66; j += 1024) tile[CB + 2 + j] = 0.0;   // the wavefronts' carry slots
     __syncthreads();
     const u32 lane = threadIdx.x & 63;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -369,7 +370,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
         // adds what follows its last piece end (its whole sum if it has none) to the slot named after the last lane
         // before it that holds a piece end; the lane holding the row's end starts its running sum from that slot.
         // One ds_add + one ds_read per lane and step, no shuffles, no scan.
-        double *carry = tile + LZX_PB_CB + 2 + wv * 66;
+        double *carry = tile + CB + 2 + wv * 66;
         auto body = [&](const uint4 &c, u32 pos) {
             double xv[8];
 #pragma unroll
@@ -722,7 +723,7 @@ int pb_units(lzx_ctx *c, hipStream_t st, const std::vector<u32> &sstart, const s
     if (c->overlap) {
         const u64 chunk0_end = (u64)c->world * c->xs0;
         u32 u0 = 0;
-        while (u0 < c->pb_units && ((u64)units[5 * u0] + 1) * LZX_PB_CB <= chunk0_end) ++u0;
+        while (u0 < c->pb_units && ((u64)units[5 * u0] + 1) * c->pb_cb <= chunk0_end) ++u0;
         c->pb_units0 = u0;
     }
     LZX_TRY(pb_alloc(&c->d_pb_unit, units.size()));
@@ -745,7 +746,10 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
 {
     hipStream_t st = c->stream;
     if (total >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu entries do not fit 32-bit slots", (unsigned long long)total);
-    const u32 nb = (u32)((c->xlen + LZX_PB_CB - 1) / LZX_PB_CB);
+    // column band = LDS tile of x: 16 Ki values; 8 Ki (two scatter workgroups per CU, more and shorter units) when x sits
+    // in the L2s anyway (C2: scatter 0.033 -> 0.024 ms; on C3 the doubled number of (row, band) pairs loses: 0.75 -> 0.87 ms)
+    c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384) ? (u32)c->pb_cb_opt : (c->xlen * sizeof(double) <= (16u << 20) ? 8192u : LZX_PB_CB);
+    const u32 nb = (u32)((c->xlen + c->pb_cb - 1) / c->pb_cb);
     if (nb >= (1u << 16)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u column bands (limit 65535)", nb);
     // values per gather item / entries per plain band: every wavefront slot of the gather pass (2 workgroups of 8 per
     // CU) should get a few items, and an item should not be shorter than its fold is worth
@@ -807,7 +811,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(ar.get(&d_keys, total)); LZX_TRY(ar.get(&d_sorted, total));
     if (c->n_loc_real)
         hipLaunchKernelGGL(k_pb_emit, dim3(c->n_loc_real), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
-                           d_old_of_local, d_deg_local, d_nh_off, c->hub_real, c->d_pb_row0, nr, d_keys);
+                           d_old_of_local, d_deg_local, d_nh_off, c->hub_real, c->d_pb_row0, nr, c->pb_cb, d_keys);
     LZX_TRY(pb_sort_keys(st, d_keys, d_sorted, total));
     ar.drop(d_keys);
 
@@ -846,7 +850,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(ar.get(&d_step_cband, (u64)nsteps + 1)); LZX_TRY(ar.get(&d_step_run, (u64)nsteps + 1));
     LZX_TRY(ar.get(&d_step_cnt, (u64)nsteps + 1)); LZX_TRY(ar.get(&d_step_excl, (u64)nsteps + 1));
     if (nsteps) {
-        hipLaunchKernelGGL(k_pb_fill16, GRID(epad_total), d_rcode, epad_total, (uint16_t)LZX_PB_CB);   // padding: the zero slot, no flag
+        hipLaunchKernelGGL(k_pb_fill16, GRID(epad_total), d_rcode, epad_total, (uint16_t)c->pb_cb);   // padding: the zero slot, no flag
         hipLaunchKernelGGL(k_pb_fill16, GRID(epad_total), d_rrow, epad_total, (uint16_t)0xffffu);
         hipLaunchKernelGGL(k_pbr_place, GRID(total), d_sorted, d_runid, d_runstart, d_estart, d_fmt, total, d_rcode, d_rrow,
                            d_step_cband, d_step_run);
@@ -877,7 +881,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(ar.get(&d_prow, len + 8)); LZX_TRY(ar.get(&d_plcol, len + 8)); LZX_TRY(ar.get(&d_qcband, nquads + 2));
     LZX_TRY(ar.get(&d_step_base, (u64)nsteps + 1));
     hipLaunchKernelGGL(k_pb_fill16, GRID(len + 8), d_prow, len + 8, (uint16_t)0xffffu);        // padding: no row
-    hipLaunchKernelGGL(k_pb_fill16, GRID(len + 8), d_plcol, len + 8, (uint16_t)LZX_PB_CB);     // padding: the zero behind the staged band
+    hipLaunchKernelGGL(k_pb_fill16, GRID(len + 8), d_plcol, len + 8, (uint16_t)c->pb_cb);     // padding: the zero behind the staged band
     hipLaunchKernelGGL(k_pb_fill16, GRID(nquads + 2), d_qcband, nquads + 2, (uint16_t)0xffffu);   // quads outside plain runs: no band
     if (nsteps) {
         hipLaunchKernelGGL(k_pbr_step_base, GRID(nsteps), d_step_run, d_estart, d_step_excl, d_vpos, nsteps, d_step_base);
@@ -1074,9 +1078,10 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                   hipEvent_t v_ready)
 {
     if (!c->pb) return LZX_OK;
-    const size_t lds1 = ((size_t)LZX_PB_CB + 2 + 16 * 66) * sizeof(double);
+    const size_t lds1 = ((size_t)c->pb_cb + 2 + 16 * 66) * sizeof(double);
     static const int ablate = getenv("LZX_ABLATE") ? atoi(getenv("LZX_ABLATE")) : 0;
-    auto kern = ablate ? k_pb_scatter<true> : k_pb_scatter<false>;
+    auto kern = c->pb_cb == 8192 ? (ablate ? k_pb_scatter<8192, true> : k_pb_scatter<8192, false>)
+                                 : (ablate ? k_pb_scatter<LZX_PB_CB, true> : k_pb_scatter<LZX_PB_CB, false>);
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     auto scatter = [&](u32 u0, u32 u1) {
