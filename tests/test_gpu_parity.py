@@ -16,10 +16,10 @@ def rel_inf(a, b):
 # engine modes: plain gather path (bit-exact body rows); propagation-blocked path (long runs cross the two passes as
 # partial row sums); the same with a tiny hub so that almost every entry goes through the blocked passes; every run
 # plain (one x value per entry); a mix of reduced and plain runs with row bands cut into many gather items and small
-# scatter units
+# scatter units (and the 16 Ki column band that graphs of this size would not get by themselves)
 MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=64),
          dict(propagation_blocking=1, pb_reduce=0),
-         dict(propagation_blocking=1, hub_entries=512, pb_reduce=1500, pb_target=1024, pb_unit=4096)]
+         dict(propagation_blocking=1, hub_entries=512, pb_reduce=1500, pb_target=1024, pb_unit=4096, pb_column_band=16384)]
 
 
 def graphs(O):
