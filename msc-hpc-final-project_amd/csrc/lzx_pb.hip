@@ -194,8 +194,9 @@ __global__ void k_pb_band_pos(const u32 *rstart, const u32 *runid_incl, const u3
     band_pos[R] = i < count ? vpos[runid_incl[i] - 1] : len;
 }
 
-// Gather order (padded), step = 64 consecutive positions counted from the start of the row band.  occ[p] = how many
-// earlier lanes of the same step carry the same row; band_rep[R] = max over the band of occ + 1.
+// Gather order (padded), step = 64 consecutive positions counted from the start of the row band (one ds_add_f64
+// instruction of k_pb_gather).  occ[p] = how many earlier lanes of the same step carry the same row; band_rep[R] = max
+// over the band of occ + 1.
 __global__ void __launch_bounds__(64)
 k_pb_occurrence(const uint16_t *prow, const u32 *rstart_pad, const u32 *band_step0, u32 nr, uint8_t *occ, u32 *band_rep)
 {
@@ -539,11 +540,26 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
         for (; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
         __builtin_amdgcn_wave_barrier();
         if (item.w == 0xffffffffu) {
-            for (u32 j = lane; j < rows; j += 64) {
-                double y = 0.0;
-                for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
-                v[row0 + j] += y;
-                dot += y * q_loc[row0 + j];
+            // fold into v: eight rows per lane at a time, all their v and q loads in flight before the first store
+            // (row by row this was a chain of up to 16 dependent memory round trips per item)
+            for (u32 j0 = lane; j0 < rows; j0 += 8 * 64) {
+                double vv[8], qq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const u32 j = j0 + u * 64;
+                    vv[u] = j < rows ? v[row0 + j] : 0.0;
+                    qq[u] = j < rows ? q_loc[row0 + j] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const u32 j = j0 + u * 64;
+                    if (j < rows) {
+                        double y = 0.0;
+                        for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                        v[row0 + j] = vv[u] + y;
+                        dot += y * qq[u];
+                    }
+                }
             }
         } else {
             for (u32 j = lane; j < rows; j += 64) {
@@ -861,7 +877,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     ar.drop(d_step_cnt);
 
     // 4. value positions: every run gets its values (pieces or entries) padded to whole 64-byte lines, in gather order
-    const u32 run_align = (c->pb_align_opt == 8 || c->pb_align_opt == 16 || c->pb_align_opt == 4) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
+    const u32 run_align = (c->pb_align_opt == 8 || c->pb_align_opt == 16) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
     u32 *d_vcount = nullptr, *d_vpos = nullptr;
     LZX_TRY(ar.get(&d_vcount, (u64)nruns + 1)); LZX_TRY(ar.get(&d_vpos, (u64)nruns + 1));
     LZX_HIP(hipMemsetAsync(d_vcount + nruns, 0, sizeof(u32), st));
