@@ -194,9 +194,18 @@ __global__ void k_pb_band_pos(const u32 *rstart, const u32 *runid_incl, const u3
     band_pos[R] = i < count ? vpos[runid_incl[i] - 1] : len;
 }
 
-// Gather order (padded), step = 64 consecutive positions counted from the start of the row band (one ds_add_f64
-// instruction of k_pb_gather).  occ[p] = how many earlier lanes of the same step carry the same row; band_rep[R] = max
-// over the band of occ + 1.
+// Which 64 values meet in one ds_add_f64 instruction of k_pb_gather (counted from the start of the row band): in every
+// whole block of 128 values lane l owns values 2 l and 2 l + 1 (one 16-byte load of values, one 4-byte load of slots),
+// so the block's two instructions add the even and the odd values; the band's tail (< 128 values) goes 64 consecutive
+// values at a time.
+__device__ __forceinline__ u32 pb_group_position(u32 band_beg, u32 band_end, u32 g, u32 lane)
+{
+    const u32 whole = (band_end - band_beg) / 128u;
+    if (g < whole * 2u) return band_beg + (g >> 1) * 128u + lane * 2u + (g & 1u);
+    return band_beg + whole * 128u + (g - whole * 2u) * 64u + lane;
+}
+
+// occ[p] = how many earlier lanes of the same instruction carry the same row; band_rep[R] = max over the band of occ + 1.
 __global__ void __launch_bounds__(64)
 k_pb_occurrence(const uint16_t *prow, const u32 *rstart_pad, const u32 *band_step0, u32 nr, uint8_t *occ, u32 *band_rep)
 {
@@ -207,7 +216,7 @@ k_pb_occurrence(const uint16_t *prow, const u32 *rstart_pad, const u32 *band_ste
         if (band_step0[mid] <= step) lo = mid; else hi = mid;
     }
     const u32 R = lo;
-    const u32 i = rstart_pad[R] + (step - band_step0[R]) * 64 + lane;
+    const u32 i = pb_group_position(rstart_pad[R], rstart_pad[R + 1], step - band_step0[R], lane);
     const u32 r = i < rstart_pad[R + 1] ? (u32)prow[i] : 0xffffu;
     const bool live = r != 0xffffu;   // padding carries 0xffff
     u32 k = 0;
@@ -525,19 +534,32 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
         const u32 slots = rows * rep;
         for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
         __builtin_amdgcn_wave_barrier();
-        u32 i = beg + lane;
-        for (; i + 7 * 64 < end; i += 8 * 64) {
-            double av[8];
+        // whole blocks of 128 values (an item begins on a block boundary of its band): lane l owns values 2 l, 2 l + 1;
+        // eight blocks in flight
+        const u32 blocks_end = beg + ((end - beg) / 128u) * 128u;
+        u32 b = beg;
+        for (; b + 8 * 128 <= blocks_end; b += 8 * 128) {
+            double2 av[8];
             u32 sv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                av[u] = val[i + u * 64];
-                sv[u] = lslot[i + u * 64];
+                av[u] = *reinterpret_cast<const double2 *>(val + b + u * 128 + lane * 2);
+                sv[u] = *reinterpret_cast<const u32 *>(lslot + b + u * 128 + lane * 2);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) atomicAdd(&ytile[sv[u]], av[u]);
+            for (int u = 0; u < 8; ++u) {
+                atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+            }
         }
-        for (; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
+        for (; b < blocks_end; b += 128) {
+            const double2 a = *reinterpret_cast<const double2 *>(val + b + lane * 2);
+            const u32 s = *reinterpret_cast<const u32 *>(lslot + b + lane * 2);
+            atomicAdd(&ytile[s & 0xffffu], a.x);
+            atomicAdd(&ytile[s >> 16], a.y);
+        }
+        // the band's tail: 64 consecutive values per instruction
+        for (u32 i = blocks_end + lane; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
         __builtin_amdgcn_wave_barrier();
         if (item.w == 0xffffffffu) {
             // fold into v: eight rows per lane at a time, all their v and q loads in flight before the first store
@@ -1030,7 +1052,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         const u32 rows = row0[R + 1] - row0[R];
         if (end - beg > 2 * target) {
             const u32 cnt = (end - beg + target - 1) / target;
-            const u32 piece = ((end - beg + cnt - 1) / cnt + 63u) & ~63u;
+            const u32 piece = ((end - beg + cnt - 1) / cnt + 127u) & ~127u;   // whole 128-value blocks of the band
             u32 made = 0;
             for (u32 s = beg; s < end; s += piece, ++made) {
                 items.push_back(R); items.push_back(s); items.push_back(std::min(end, s + piece));
