@@ -352,12 +352,14 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
              const double *__restrict__ x, u64 xlen, double *val, int ablate_arg)
 {
     const int ablate = DBG ? ablate_arg : 0;
+    const bool ab_store = ablate == 6 || ablate == 9, ab_lds = ablate == 7 || ablate == 9, ab_carry = ablate == 8 || ablate == 9;
     extern __shared__ __attribute__((aligned(16))) double tile[];   // CB staged values + a zero for padding
     const u32 band = unit[5 * blockIdx.x];
     const u64 base = (u64)band * CB;
     // staging is dead time for this CU (the tile leaves room for one workgroup): all eight 16-byte loads of a
     // thread are issued before the first LDS write, so it costs one memory round trip
-    if (base + CB <= xlen) {
+    if (ablate == 10) {
+    } else if (base + CB <= xlen) {
         const double2 *src = reinterpret_cast<const double2 *>(x + base);   // band starts are 128 KiB aligned
         double2 t[CB / 2048];
 #pragma unroll
@@ -384,7 +386,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
         auto body = [&](const uint4 &c, u32 pos) {
             double xv[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = ablate == 7 ? (double)pbr_half(c, e) : tile[pbr_half(c, e) & 0x7fffu];
+            for (int e = 0; e < 8; ++e) xv[e] = ab_lds ? (double)pbr_half(c, e) : tile[pbr_half(c, e) & 0x7fffu];
             u32 ends = 0;   // bit e: entry e closes a piece
 #pragma unroll
             for (int e = 0; e < 8; ++e) ends |= pbr_flag(c, e) << e;
@@ -398,7 +400,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
             const unsigned long long before = holders & ((1ull << lane) - 1ull);
             const u32 from = before ? 64u - (u32)__clzll((long long)before) : 0u;   // 1 + last holder before this lane
             double s = 0.0;
-            if (ablate != 8) {
+            if (!ab_carry) {
             atomicAdd(&carry[has ? lane + 1 : from], tail);
             __builtin_amdgcn_wave_barrier();
             s = has ? carry[from] : 0.0;
@@ -414,7 +416,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
                 const unsigned long long m = __ballot(f);
                 if (m) {               // scalar branch: steps of few long rows have mostly empty planes
                     if (f) {
-                        if (ablate != 6 || s == 1.2345e-300) out[done + lanes_below(m)] = s;
+                        if (!ab_store || s == 1.2345e-300) out[done + lanes_below(m)] = s;
                         s = 0.0;
                     }
                     done += (u32)__popcll(m);
@@ -797,13 +799,14 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         target = (u32)std::min<u64>(LZX_PB_TARGET, std::max<u64>(4096, (want + 1023) & ~1023ull));
     }
     if (c->pb_target_opt > 0) target = (u32)c->pb_target_opt;
-    // entries per scatter unit: every unit restages its 128 KiB column band while its CU does nothing else, but small
-    // units even out the tail: 64 Ki entries (measured on C3 and its 1/4 and 1/8 rank shares, tools/rank_probe.py:
-    // 16 Ki .. 1 Mi tried, 64 Ki best or tied everywhere); smaller, down to 8 Ki, only to give every CU about four
-    // units on graphs whose x sits in the L2s anyway
-    u32 unit_cap = 65536;
+    // entries per scatter unit: every unit restages its column band while its CU does nothing else, and a workgroup
+    // only leaves its CU to the next one when its last wavefront is done, so big units are cheaper; small ones even out
+    // the tail.  About four units per CU, between 64 Ki and 128 Ki entries (measured, tools/perf_probe.py @unit and
+    // tools/rank_probe.py: C3 on one GPU 128 Ki 0.317 vs 64 Ki 0.344 vs 256 Ki 0.326 ms; its 1/8 share 64 Ki best);
+    // down to 8 Ki only to give every CU about four units on graphs whose x sits in the L2s anyway
+    u32 unit_cap = (u32)std::min<u64>(131072, std::max<u64>(65536, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
     if (c->xlen * sizeof(double) <= (16u << 20))
-        unit_cap = (u32)std::min<u64>(unit_cap, std::max<u64>(8192, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
+        unit_cap = (u32)std::min<u64>(65536, std::max<u64>(8192, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
     if (c->pb_unit_opt > 0) unit_cap = (u32)c->pb_unit_opt;
 
     // ---- row bands: consecutive local rows (they are in descending degree order): as many rows as the wave-private
