@@ -232,7 +232,6 @@ int lzx_graph_prepare(lzx_ctx *c)
     const u32 world = (u32)c->world, rank = (u32)c->rank;
     if (n == 0) LZX_FAIL(LZX_ERR_ARG, "graph has no vertices");
     if (n >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "n = %llu: this build indexes vertices with 31 bits", (unsigned long long)n);
-    if (c->nnz >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "nnz = %llu >= 2^32 is not supported yet", (unsigned long long)c->nnz);
 
     hipStream_t st = c->stream;
     const u32 per = (u32)((n + world - 1) / world);
@@ -359,6 +358,9 @@ int lzx_graph_prepare(lzx_ctx *c)
     PREP_HIP(hipStreamSynchronize(st));
     c->nnz_local = 0;
     for (u32 l = 0; l < c->n_loc_real; ++l) c->nnz_local += degl[l];
+    // the whole graph may hold more than 2^32 entries (every rank keeps all of it: C5's 4e9 entries are 17 GB of the
+    // 288 GB); a rank's own share is indexed with 32 bits
+    if (c->nnz_local >= (1ull << 32)) { cleanup(); LZX_FAIL(LZX_ERR_LIMIT, "%llu entries in this rank's rows: use more ranks (limit 2^32 per rank)", (unsigned long long)c->nnz_local); }
 
     // propagation-blocking mode: k_spmv keeps only the hub entries of each row; `degl` becomes that count
     u64 pb_total = 0;
@@ -546,7 +548,6 @@ static int csr_from_keys_dev(lzx_ctx *c, u64 n, u64 *d_keys, u64 nkeys)
 #define ING_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); \
         return e_ == hipErrorOutOfMemory ? LZX_ERR_NOMEM : LZX_ERR_HIP; } } while (0)
-    if (nkeys >= (1ull << 31)) { cleanup(); LZX_FAIL(LZX_ERR_LIMIT, "edge list too long for one sort (%llu keys)", (unsigned long long)nkeys); }
     ING(dev_alloc(&d_sorted, nkeys)); ING(dev_alloc(&d_count, 1));
     size_t tb = 0;
     ING_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_keys, d_sorted, (u64)nkeys, 0, 64, st));

@@ -142,3 +142,38 @@ def test_edge_cases(pkg, oracle):
     with pytest.raises(pkg.LzxError):
         eng.set_option("hub_entries", 4)                    # options are fixed once the graph is in
     eng.close()
+
+
+def test_c5_size_graph(pkg):
+    """BASELINE C5's graph (R-MAT, 100 M vertices, 2 G draws -> 3.9 G stored entries, more than 2^32): every rank keeps
+    the whole graph (17 GB of the 288 GB) and reshapes its own rows.  Rank 0 of 8 on this one GPU: its share and its
+    blocked tables; then one handle in plain mode, where the whole SpMV can be checked through size-independent
+    properties (one rank's blocked tables would exceed their 31-bit slots -- that must be refused, not attempted)."""
+    scale, n, draws = 27, 100_000_000, 2_000_000_000
+    grp = pkg.LocalGroup([0] * 8)
+    e0 = grp.engines[0]
+    e0.gen_rmat(scale, n, draws, 1234)
+    gi = e0.info()
+    assert gi["nnz"] > 2 ** 32 - 2 ** 29 and gi["rows_local"] == n // 8
+    assert abs(gi["nnz_local"] * 8 - gi["nnz"]) <= 0.01 * gi["nnz"]          # rows dealt by degree rank: balanced
+    assert 0 < gi["pb_values"] < gi["pb_entries"] < gi["nnz_local"] and gi["pb_reduced_entries"] > gi["pb_entries"] // 2
+    avg, mn = e0.bench_spmv(3)
+    assert 0 < mn <= avg
+    grp.close()
+
+    eng = pkg.Engine(0)                     # one rank, blocked mode (the default at this size): over the limit
+    with pytest.raises(pkg.LzxError):
+        eng.gen_rmat(scale, n, draws, 1234)
+    eng.close()
+
+    eng = pkg.Engine(0, propagation_blocking=0)
+    eng.gen_rmat(scale, n, draws, 1234)
+    g1 = eng.info()
+    assert g1["nnz"] == gi["nnz"] and g1["max_degree"] == gi["max_degree"]
+    y = eng.spmv(np.ones(n))
+    assert float(y.sum()) == float(g1["nnz"]) and y.max() == g1["max_degree"] and np.array_equal(y, np.rint(y))
+    rng = np.random.default_rng(7)
+    a, b = rng.random(n), rng.random(n)
+    Aa, Ab = eng.spmv(a), eng.spmv(b)
+    assert abs(a @ Ab - b @ Aa) <= 1e-12 * abs(a @ Ab)
+    eng.close()

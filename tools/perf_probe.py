@@ -9,7 +9,8 @@ import numpy as np
 import __graft_entry__ as ge
 
 pkg = ge.load_pkg()
-WORK = {"c2": (20, 1 << 20, 20_000_000), "c3": (24, 10_000_000, 200_000_000), "c2b": (20, 1_000_000, 20_000_000)}
+WORK = {"c2": (20, 1 << 20, 20_000_000), "c3": (24, 10_000_000, 200_000_000), "c2b": (20, 1_000_000, 20_000_000),
+        "big": (25, 30_000_000, 600_000_000)}
 
 
 def run(name, opts_list, k=20):
