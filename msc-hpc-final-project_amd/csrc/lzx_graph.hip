@@ -154,20 +154,23 @@ __global__ void k_fill_long(const u64 *row_ptr, const u32 *col_idx, const u32 *c
         long_cols[beg + k] = (k < d) ? code_of_old[col_idx[base + k]] : sentinel;
 }
 
-// entries of each local row whose column is staged in LDS (code < hub); one wavefront per row
+// entries of each local row whose column is staged in LDS (code < hub); one wavefront per row, rows strided over the
+// grid (a launch holds at most 2^32 work-items: one block per row wrapped silently from 67 M rows)
 __global__ void __launch_bounds__(64)
 k_row_hub_count(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, const u32 *old_of_local,
-                const u32 *deg_local, u32 hub, u32 *hub_deg, u32 *nonhub_deg)
+                const u32 *deg_local, u32 n_rows, u32 hub, u32 *hub_deg, u32 *nonhub_deg)
 {
-    const u32 l = blockIdx.x, lane = threadIdx.x;
-    const u32 d = deg_local[l];
-    const u64 base = row_ptr[old_of_local[l]];
-    u32 cnt = 0;
-    for (u32 k = lane; k < d; k += 64) cnt += code_of_old[col_idx[base + k]] < hub;
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) {
-        hub_deg[l] = cnt;
-        nonhub_deg[l] = d - cnt;
+    const u32 lane = threadIdx.x;
+    for (u32 l = blockIdx.x; l < n_rows; l += gridDim.x) {
+        const u32 d = deg_local[l];
+        const u64 base = row_ptr[old_of_local[l]];
+        u32 cnt = 0;
+        for (u32 k = lane; k < d; k += 64) cnt += code_of_old[col_idx[base + k]] < hub;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) {
+            hub_deg[l] = cnt;
+            nonhub_deg[l] = d - cnt;
+        }
     }
 }
 
@@ -368,8 +371,8 @@ int lzx_graph_prepare(lzx_ctx *c)
         PREP(dev_alloc(&d_hub_deg, c->n_loc_real)); PREP(dev_alloc(&d_nh_deg, (u64)c->n_loc_real + 1));
         PREP(dev_alloc(&d_nh_off, (u64)c->n_loc_real + 1));
         PREP_HIP(hipMemsetAsync(d_nh_deg, 0, sizeof(u32) * ((u64)c->n_loc_real + 1), st));
-        hipLaunchKernelGGL(k_row_hub_count, dim3(c->n_loc_real), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
-                           d_old_of_local, d_deg_local, c->hub_real, d_hub_deg, d_nh_deg);
+        hipLaunchKernelGGL(k_row_hub_count, dim3(std::min<u32>(c->n_loc_real, 1u << 22)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx,
+                           d_code, d_old_of_local, d_deg_local, c->n_loc_real, c->hub_real, d_hub_deg, d_nh_deg);
         h_nh.assign(c->n_loc_real, 0);
         PREP_HIP(hipMemcpyAsync(degl.data(), d_hub_deg, sizeof(u32) * c->n_loc_real, hipMemcpyDeviceToHost, st));
         PREP_HIP(hipMemcpyAsync(h_nh.data(), d_nh_deg, sizeof(u32) * c->n_loc_real, hipMemcpyDeviceToHost, st));
@@ -377,7 +380,7 @@ int lzx_graph_prepare(lzx_ctx *c)
         u64 hub_total = 0;
         for (u32 l = 0; l < c->n_loc_real; ++l) hub_total += degl[l];
         pb_total = c->nnz_local - hub_total;
-        if (pb_total >= (1ull << 31)) {
+        if (pb_total >= LZX_PB_SLOT_LIMIT) {
             lzx_set_error("propagation blocking: %llu entries on this rank exceed the 32-bit slot range", (unsigned long long)pb_total);
             cleanup();
             return LZX_ERR_LIMIT;
@@ -548,6 +551,8 @@ static int csr_from_keys_dev(lzx_ctx *c, u64 n, u64 *d_keys, u64 nkeys)
 #define ING_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); \
         return e_ == hipErrorOutOfMemory ? LZX_ERR_NOMEM : LZX_ERR_HIP; } } while (0)
+    // one work-item per key below, and a launch holds at most 2^32 of them
+    if (nkeys >= (1ull << 32) - (1ull << 24)) { cleanup(); LZX_FAIL(LZX_ERR_LIMIT, "edge list too long for one ingest (%llu directed entries)", (unsigned long long)nkeys); }
     ING(dev_alloc(&d_sorted, nkeys)); ING(dev_alloc(&d_count, 1));
     size_t tb = 0;
     ING_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_keys, d_sorted, (u64)nkeys, 0, 64, st));

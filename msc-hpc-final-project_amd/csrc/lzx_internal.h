@@ -57,6 +57,9 @@ static constexpr u32 LZX_PB_RB = 1024;
 static constexpr u32 LZX_PB_TARGET = 32768;   // upper limit of the values per gather item (one wavefront each)
 static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
+// entries, padded entries and values of one rank's blocked tables are indexed with 32 bits (a margin is left for the
+// kernels' look-ahead)
+static constexpr u64 LZX_PB_SLOT_LIMIT = (1ull << 32) - (1ull << 24);
 // reduced runs (partial row sums instead of single values cross the two passes)
 static constexpr u32 LZX_PBR_STEP = 512;      // entries per wavefront step; reduced runs are padded to whole steps
 static constexpr u32 LZX_PBR_MIN_RUN = 384;   // a (row band, column band) run of at least this many entries is reduced

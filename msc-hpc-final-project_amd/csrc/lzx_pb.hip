@@ -45,37 +45,40 @@ __device__ __forceinline__ u64 pack_key(u32 rband, u32 cband, u32 lrow, u32 lcol
     return ((u64)rband << 40) | ((u64)cband << 24) | ((u64)lrow << 14) | (u64)lcol;
 }
 
-// one wavefront (64-thread block) per local row: keep the entries whose code is not a hub slot
+// one wavefront (64-thread block) per local row, rows strided over the grid (a launch holds at most 2^32 work-items):
+// keep the entries whose code is not a hub slot
 __global__ void __launch_bounds__(64)
 k_pb_emit(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, const u32 *old_of_local,
-          const u32 *deg_local, const u32 *nh_off, u32 hub, const u32 *band_row0, u32 nr, u32 cb, u64 *keys)
+          const u32 *deg_local, const u32 *nh_off, u32 n_rows, u32 hub, const u32 *band_row0, u32 nr, u32 cb, u64 *keys)
 {
-    const u32 l = blockIdx.x, lane = threadIdx.x;
-    const u32 d = deg_local[l];
-    // row band of local row l: last band whose first row is <= l
-    u32 lo = 0, hi = nr;
-    while (hi - lo > 1) {
-        const u32 mid = (lo + hi) >> 1;
-        if (band_row0[mid] <= l) lo = mid; else hi = mid;
-    }
-    const u32 R = lo, lrow = l - band_row0[lo];
-    const u64 base = row_ptr[old_of_local[l]];
-    u32 out = nh_off[l];
-    for (u32 k0 = 0; k0 < d; k0 += 64) {
-        const u32 k = k0 + lane;
-        u32 cde = 0;
-        bool keep = false;
-        if (k < d) {
-            cde = code_of_old[col_idx[base + k]];
-            keep = cde >= hub;
+    const u32 lane = threadIdx.x;
+    for (u32 l = blockIdx.x; l < n_rows; l += gridDim.x) {
+        const u32 d = deg_local[l];
+        // row band of local row l: last band whose first row is <= l
+        u32 lo = 0, hi = nr;
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (band_row0[mid] <= l) lo = mid; else hi = mid;
         }
-        const unsigned long long m = __ballot(keep);
-        if (keep) {
-            const u32 p = cde - hub;
-            const u32 pre = __popcll(m & ((1ull << lane) - 1ull));
-            keys[out + pre] = pack_key(R, p / cb, lrow, p % cb);
+        const u32 R = lo, lrow = l - band_row0[lo];
+        const u64 base = row_ptr[old_of_local[l]];
+        u32 out = nh_off[l];
+        for (u32 k0 = 0; k0 < d; k0 += 64) {
+            const u32 k = k0 + lane;
+            u32 cde = 0;
+            bool keep = false;
+            if (k < d) {
+                cde = code_of_old[col_idx[base + k]];
+                keep = cde >= hub;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const u32 p = cde - hub;
+                const u32 pre = __popcll(m & ((1ull << lane) - 1ull));
+                keys[out + pre] = pack_key(R, p / cb, lrow, p % cb);
+            }
+            out += __popcll(m);
         }
-        out += __popcll(m);
     }
 }
 
@@ -785,7 +788,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
                     const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total)
 {
     hipStream_t st = c->stream;
-    if (total >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu entries do not fit 32-bit slots", (unsigned long long)total);
+    if (total >= LZX_PB_SLOT_LIMIT) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu entries do not fit 32-bit slots", (unsigned long long)total);
     // column band = LDS tile of x: 16 Ki values; 8 Ki (two scatter workgroups per CU, more and shorter units) when x sits
     // in the L2s anyway (C2: scatter 0.033 -> 0.024 ms; on C3 the doubled number of (row, band) pairs loses: 0.75 -> 0.87 ms)
     c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384) ? (u32)c->pb_cb_opt : (c->xlen * sizeof(double) <= (16u << 20) ? 8192u : LZX_PB_CB);
@@ -851,8 +854,8 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     u64 *d_keys = nullptr, *d_sorted = nullptr;
     LZX_TRY(ar.get(&d_keys, total)); LZX_TRY(ar.get(&d_sorted, total));
     if (c->n_loc_real)
-        hipLaunchKernelGGL(k_pb_emit, dim3(c->n_loc_real), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
-                           d_old_of_local, d_deg_local, d_nh_off, c->hub_real, c->d_pb_row0, nr, c->pb_cb, d_keys);
+        hipLaunchKernelGGL(k_pb_emit, dim3(std::min<u32>(c->n_loc_real, 1u << 22)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_code,
+                           d_old_of_local, d_deg_local, d_nh_off, c->n_loc_real, c->hub_real, c->d_pb_row0, nr, c->pb_cb, d_keys);
     LZX_TRY(pb_sort_keys(st, d_keys, d_sorted, total));
     ar.drop(d_keys);
 
@@ -877,7 +880,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         LZX_TRY(pb_download(st, d_epad, nruns, h));
         u64 sum = 0;
         for (u32 v : h) sum += v;
-        if (sum >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu padded entries do not fit 32-bit slots", (unsigned long long)sum);
+        if (sum >= LZX_PB_SLOT_LIMIT) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu padded entries do not fit 32-bit slots", (unsigned long long)sum);
         epad_total = (u32)sum;
     }
     LZX_TRY(pb_scan(st, false, d_epad, d_estart, (u64)nruns + 1));
@@ -912,7 +915,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         std::vector<u32> h;
         LZX_TRY(pb_download(st, d_vcount, nruns, h));
         for (u32 v : h) len += v;
-        if (len >= (1ull << 31)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu values do not fit 32-bit slots", (unsigned long long)len);
+        if (len >= LZX_PB_SLOT_LIMIT) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu values do not fit 32-bit slots", (unsigned long long)len);
     }
     LZX_TRY(pb_scan(st, false, d_vcount, d_vpos, (u64)nruns + 1));
     ar.drop(d_vcount);

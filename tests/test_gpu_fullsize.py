@@ -147,8 +147,8 @@ def test_edge_cases(pkg, oracle):
 def test_c5_size_graph(pkg):
     """BASELINE C5's graph (R-MAT, 100 M vertices, 2 G draws -> 3.9 G stored entries, more than 2^32): every rank keeps
     the whole graph (17 GB of the 288 GB) and reshapes its own rows.  Rank 0 of 8 on this one GPU: its share and its
-    blocked tables; then one handle in plain mode, where the whole SpMV can be checked through size-independent
-    properties (one rank's blocked tables would exceed their 31-bit slots -- that must be refused, not attempted)."""
+    blocked tables.  Then the whole graph on ONE handle (3.3 G blocked entries, beyond 2^31): size-independent
+    properties of the SpMV and of three Lanczos iterations."""
     scale, n, draws = 27, 100_000_000, 2_000_000_000
     grp = pkg.LocalGroup([0] * 8)
     e0 = grp.engines[0]
@@ -161,19 +161,24 @@ def test_c5_size_graph(pkg):
     assert 0 < mn <= avg
     grp.close()
 
-    eng = pkg.Engine(0)                     # one rank, blocked mode (the default at this size): over the limit
-    with pytest.raises(pkg.LzxError):
-        eng.gen_rmat(scale, n, draws, 1234)
-    eng.close()
-
-    eng = pkg.Engine(0, propagation_blocking=0)
+    eng = pkg.Engine(0)
     eng.gen_rmat(scale, n, draws, 1234)
     g1 = eng.info()
-    assert g1["nnz"] == gi["nnz"] and g1["max_degree"] == gi["max_degree"]
-    y = eng.spmv(np.ones(n))
+    assert g1["nnz"] == gi["nnz"] and g1["max_degree"] == gi["max_degree"] and g1["pb_entries"] > 2 ** 31
+    y = eng.spmv(np.ones(n))                                  # row sums = degrees: integers, exactly
     assert float(y.sum()) == float(g1["nnz"]) and y.max() == g1["max_degree"] and np.array_equal(y, np.rint(y))
+    assert int((y > 0).sum()) == g1["active_vertices"]
     rng = np.random.default_rng(7)
     a, b = rng.random(n), rng.random(n)
     Aa, Ab = eng.spmv(a), eng.spmv(b)
-    assert abs(a @ Ab - b @ Aa) <= 1e-12 * abs(a @ Ab)
+    assert abs(a @ Ab - b @ Aa) <= 1e-12 * abs(a @ Ab)        # symmetric
+    al, be, Q, xn, st = eng.lanczos(np.ones(n), 3)
+    assert xn == np.sqrt(float(n)) and abs(al[0] - g1["nnz"] / n) <= 1e-12 * al[0]   # alpha_0 = 1'A1 / n
+    scale_t = max(np.abs(al).max(), np.abs(be).max())
+    for j in range(2):
+        r = eng.spmv(Q[j]) - al[j] * Q[j] - be[j] * Q[j + 1]
+        if j > 0:
+            r -= be[j - 1] * Q[j - 1]
+        assert np.abs(r).max() <= 1e-12 * scale_t, j
+        assert abs(np.sqrt(np.sum(Q[j] * Q[j])) - 1.0) <= 1e-12, j    # (1e8 terms: the host's own summation error)
     eng.close()
