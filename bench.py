@@ -33,8 +33,8 @@ WORKLOADS = {
            1 << 20, 20_000_000, 1234, 50),
     "c3": ("C3/C4: R-MAT scale 24 (a,b,c,d)=(.57,.19,.19,.05), endpoints >= n re-drawn, n=10,000,000, "
            "200M draws, seed 1234", "rmat", 24, 10_000_000, 200_000_000, 1234, 50),
-    # 3.9e9 stored entries: needs >= 2 GPUs (one rank's blocked tables are limited to 2^31 values); every rank generates
-    # and keeps the whole graph (17 GB) and reshapes its own rows.  cpu_baseline is skipped at this size.
+    # 3.9e9 stored entries (> 2^32): every rank generates and keeps the whole graph (17 GB) and reshapes its own rows; fits
+    # one MI355X too (about 100 iter/s there).  Use --no-cpu-baseline at N = 1: the host loop takes minutes per iteration.
     "c5": ("C5: R-MAT scale 27 (a,b,c,d)=(.57,.19,.19,.05), endpoints >= n re-drawn, n=100,000,000, 2G draws, "
            "seed 1234", "rmat", 27, 100_000_000, 2_000_000_000, 1234, 30),
 }
