@@ -221,6 +221,7 @@ def main():
                              f"all-gather of {8 * gi['exchange_slice']} B per rank (only the {gi['active_vertices']} "
                              f"vertices that have an edge are exchanged; the vector travels unnormalised) + 1 two-double all-reduce",
                 "exchange_tuning_ms_per_iter": tune or None,
+                "exchange_chunk0_doubles_per_rank": gi.get("exchange_chunk0", 0),
                 "graph_build_s": round(t_gen, 3),
                 # not `value`: the same K iterations with the host hand-over (x0 upload, basis set-up) and the download
                 # of alpha / beta included -- what a caller holding host buffers sees (rank 0's clock)

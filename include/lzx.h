@@ -71,6 +71,8 @@ typedef struct lzx_graph_info {
     uint32_t reserved_;
     uint64_t pb_values;   /* values the blocked scatter passes hand to the gather pass per SpMV (padding included) */
     uint64_t pb_reduced_entries; /* of pb_entries: entries of the reduced bands, which travel as partial row sums */
+    uint64_t exchange_chunk0;    /* doubles per rank in the first of the two all-gathers that overlap the blocked SpMV
+                                    (0 = one all-gather per iteration) */
 } lzx_graph_info;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -177,7 +179,7 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  *                           beta come out of one reduction per iteration (one 2-double all-reduce) and one vector kernel;
  *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on
  *                           one GPU in plain mode
- *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "pb_column_band", "side_stream"
+ *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "pb_column_band", "side_stream", "exchange_at_world_1"
  *                           experiment knobs behind DESIGN.md's tuning log (tools/perf_probe.py)               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);
 

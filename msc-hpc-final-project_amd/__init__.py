@@ -38,7 +38,8 @@ class LzxGraphInfo(ctypes.Structure):
                 ("long_rows", ctypes.c_uint64), ("sell_padded", ctypes.c_uint64),
                 ("pb_entries", ctypes.c_uint64), ("active_vertices", ctypes.c_uint64),
                 ("exchange_slice", ctypes.c_uint64), ("hub_entries", ctypes.c_uint32), ("world", ctypes.c_uint32), ("rank", ctypes.c_uint32),
-                ("reserved_", ctypes.c_uint32), ("pb_values", ctypes.c_uint64), ("pb_reduced_entries", ctypes.c_uint64)]
+                ("reserved_", ctypes.c_uint32), ("pb_values", ctypes.c_uint64), ("pb_reduced_entries", ctypes.c_uint64),
+                ("exchange_chunk0", ctypes.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -107,6 +107,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
+    else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
@@ -210,8 +211,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     LZX_TRY(check_graphs(cs));
     lzx_ctx *c0 = cs[0];
     const u64 n = c0->n;
-    const int world = c0->world;
-    const bool multi = world > 1;
+    const bool multi = lzx_exchanges(c0);
 
     // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161).
     double ss = 0.0;
@@ -249,8 +249,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     const u32 k = c0->k_prep;
     for (lzx_ctx *c : cs)
         if (c->k_prep == 0 || c->k_prep != k) LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_run: no prepared start vector");
-    const int world = c0->world;
-    const bool multi = world > 1;
+    const bool multi = lzx_exchanges(c0);
     LZX_TRY(sync_all(cs));
 
     Marks mk{c0};
@@ -482,7 +481,7 @@ static int lanczos_fetch(std::vector<lzx_ctx *> &cs, u32 k, double *alpha, doubl
     lzx_ctx *c0 = cs[0];
     if (c0->k_last < k) LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_fetch: only %u iterations are resident", c0->k_last);
     const u64 n = c0->n;
-    const bool multi = c0->world > 1;
+    const bool multi = lzx_exchanges(c0);
     std::vector<const double *> src(cs.size());
     std::vector<double *> dst(cs.size());
     LZX_HIP(hipSetDevice(c0->device));
@@ -568,7 +567,7 @@ static int spmv_run(std::vector<lzx_ctx *> &cs, const double *x, double *y)
     if (!x || !y) LZX_FAIL(LZX_ERR_ARG, "lzx_spmv_f64: bad argument");
     LZX_TRY(check_graphs(cs));
     lzx_ctx *c0 = cs[0];
-    const bool multi = c0->world > 1;
+    const bool multi = lzx_exchanges(c0);
     std::vector<const double *> src(cs.size());
     std::vector<double *> dst(cs.size());
     for (lzx_ctx *c : cs) {
@@ -610,7 +609,7 @@ static int multout_run(std::vector<lzx_ctx *> &cs, const double *t, u32 k, doubl
     if (!t || !ans || k == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_multout_f64: bad argument");
     LZX_TRY(check_graphs(cs));
     lzx_ctx *c0 = cs[0];
-    const bool multi = c0->world > 1;
+    const bool multi = lzx_exchanges(c0);
     for (lzx_ctx *c : cs)
         if (c->k_last < k) LZX_FAIL(LZX_ERR_STATE, "lzx_multout_f64: the resident basis has %u vectors, %u asked", c->k_last, k);
     std::vector<const double *> src(cs.size());
@@ -656,8 +655,8 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
     std::vector<double> ones(c->n, 1.0);
     LZX_HIP(hipMemcpyAsync(c->d_io, ones.data(), sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
     LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_ybuf, 1.0));
-    if (c->world > 1) LZX_TRY(lzx_launch_relayout(c, c->d_ybuf, c->d_xbuf));
-    SpmvLaunch l{c->world > 1 ? c->d_xbuf : c->d_ybuf, c->d_ybuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
+    if (lzx_exchanges(c)) LZX_TRY(lzx_launch_relayout(c, c->d_ybuf, c->d_xbuf));
+    SpmvLaunch l{lzx_exchanges(c) ? c->d_xbuf : c->d_ybuf, c->d_ybuf + (size_t)c->rank * c->n_loc_pad, c->d_v, c->d_partials};
     LZX_TRY(lzx_launch_spmv(c, l));  // warm-up
     LZX_HIP(hipStreamSynchronize(c->stream));
     double total = 0.0, best = 1e300;

@@ -167,7 +167,7 @@ __global__ void k_sum_ranks_n(const double *vals, int world, u32 count, double *
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count)
 {
     lzx_ctx *c0 = cs[0];
-    if (c0->world == 1) return LZX_OK;
+    if (!lzx_exchanges(c0)) return LZX_OK;
     if (c0->comm_kind == 2) {
         LZX_NCCL(g_rccl.AllReduce(c0->d_scal + slot, c0->d_scal + slot, count, ncclDouble, ncclSum,
                                   static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
@@ -195,7 +195,7 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
 {
     lzx_ctx *c0 = cs[0];
     if (cnt == 0) return LZX_OK;
-    if (c0->world == 1) {
+    if (!lzx_exchanges(c0)) {
         if (dst_full[0] != src_loc[0])
             LZX_HIP(hipMemcpyAsync(dst_full[0], src_loc[0], cnt * sizeof(double), hipMemcpyDeviceToDevice, pick(c0, on_stream2)));
         return LZX_OK;

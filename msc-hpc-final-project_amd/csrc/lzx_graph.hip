@@ -325,7 +325,7 @@ int lzx_graph_prepare(lzx_ctx *c)
     // of every slice, rounded so that chunk 0 ends on a column-band boundary, and must hold the LDS-staged hub entries.
     c->xs0 = c->xs;
     c->overlap = false;
-    if (world > 1 && pb && c->overlap_opt != 0) {
+    if ((world > 1 || c->force_multi) && pb && c->overlap_opt != 0) {
         u32 x0 = round_up(std::max<u32>(c->xs / 8, (c->hub_real + world - 1) / world), LZX_PB_CB);
         if (x0 < c->xs) {
             c->xs0 = x0;
@@ -736,6 +736,7 @@ extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
     o->pb_values = c->pb ? c->pb_values : 0;
     o->pb_reduced_entries = c->pb ? c->pbr_entries : 0;
     o->reserved_ = 0;
+    o->exchange_chunk0 = c->overlap ? c->xs0 : 0;
     o->active_vertices = c->n_active;
     o->exchange_slice = c->world > 1 ? c->xs : 0;
     o->world = (uint32_t)c->world;

@@ -116,6 +116,7 @@ struct lzx_ctx {
     u32 pb_units0 = 0;                 // scatter units whose column band lies wholly in chunk 0
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
+    bool force_multi = false;          // test hook: a 1-rank RCCL communicator runs the several-rank code path, collectives included
     int64_t lazy_opt = -1;             // lazy normalisation (lzx_api.hip): -1 = with several ranks and in blocked mode, 0 off, 1 on
     int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
     int64_t pb_cb_opt = -1;            // column band override (8192 or 16384)
@@ -240,6 +241,8 @@ int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_la
 int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc);
 
 // ---- lzx_comm.hip ----
+// does the Lanczos loop exchange vectors / reduce scalars through the communicator?
+inline bool lzx_exchanges(const lzx_ctx *c) { return c->world > 1 || (c->force_multi && c->comm_kind == 2); }
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count = 1);   // d_scal[slot .. slot+count) on every handle
 int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t count,
                        bool on_stream2 = false);

@@ -196,6 +196,7 @@ def test_local_group_overlapped_exchange(oracle, pkg):
         grp.set_graph_csr(rp, ci)
         gi = grp.engines[1].info()
         assert gi["pb_entries"] > 0 and 0 < gi["exchange_slice"] <= -(-gi["active_vertices"] // 3 // 64) * 64 + 64
+        assert (gi["exchange_chunk0"] > 0) == (overlap == 1)
         assert (gi["pb_reduced_entries"] > gi["pb_entries"] // 2) == (min_run == 128), (overlap, min_run, gi)
         assert np.allclose(grp.spmv(x), y_ref, rtol=1e-13, atol=0)
         a, b, Q, xn, st = grp.lanczos(x0, k)
@@ -212,14 +213,41 @@ def test_local_group_overlapped_exchange(oracle, pkg):
 
 
 def test_rccl_world1(oracle, pkg):
-    """RCCL transport at world = 1: communicator creation, symbol resolution, stream plumbing."""
+    """RCCL transport at world = 1: communicator creation, symbol resolution, stream plumbing -- and, with the test hook
+    `exchange_at_world_1`, the several-rank loop itself on that communicator: ncclAllReduce of two doubles, ncclAllGather
+    of the exchanged prefix, lazy normalisation and the reference's order, plain and blocked SpMV.  (Two ranks cannot
+    share the one GPU of the test box under RCCL; the N > 1 arithmetic is covered by the in-process groups above.)"""
     O = oracle
     rp, ci = O.gen_er(4000, 30000, 2)
-    eng = pkg.Engine(0)
+    n, k = 4000, 10
+    x0 = np.ones(n)
+    a_ref, b_ref, Q_ref, xn_ref, ans_ref = pipeline_ref(O, rp, ci, k, x0)
+    x = np.random.default_rng(3).random(n)
+    for mode in (dict(), dict(exchange_at_world_1=1), dict(exchange_at_world_1=1, lazy_normalisation=0),
+                 dict(exchange_at_world_1=1, propagation_blocking=1, hub_entries=256)):
+        eng = pkg.Engine(0, **mode)
+        eng.comm_init_rank(pkg.Engine.unique_id(), 0, 1)
+        eng.set_graph_csr(rp, ci)
+        assert np.allclose(eng.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0), mode
+        a, b, Q, xn, st = eng.lanczos(x0, k)
+        check_leading_coefficients(a, b, a_ref, b_ref, ("rccl1", mode))
+        check_recurrence(O, rp, ci, a, b, Q, ("rccl1", mode))
+        lam, V = O.eigen(a, b)
+        assert rel_inf(eng.multout(V @ (np.exp(lam) * (xn * V[0, :]))), ans_ref) <= REL_INF_TOL, mode
+        if mode.get("exchange_at_world_1"):
+            assert st["comm_ms"] >= 0.0 and st["iters"] == k
+        eng.close()
+    # the two-chunk exchange on the second stream (blocked SpMV starting on chunk 0), same hook, a graph large enough
+    rp, ci = O.gen_er(300000, 1500000, 5)
+    n = len(rp) - 1
+    x = np.random.default_rng(4).random(n)
+    eng = pkg.Engine(0, exchange_at_world_1=1, propagation_blocking=1, hub_entries=1024)
     eng.comm_init_rank(pkg.Engine.unique_id(), 0, 1)
     eng.set_graph_csr(rp, ci)
-    a, b, Q, xn, st = eng.lanczos(np.ones(4000), 10)
-    a_ref, b_ref, _, _ = O.lanczos(rp, ci, 10, np.ones(4000))
-    check_leading_coefficients(a, b, a_ref, b_ref, "rccl1")
-    check_recurrence(O, rp, ci, a, b, Q, "rccl1")
+    assert eng.info()["exchange_chunk0"] > 0 and eng.info()["pb_entries"] > 0
+    assert np.allclose(eng.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+    a, b, Q, xn, st = eng.lanczos(np.ones(n), 8)
+    a_ref, b_ref, _, _ = O.lanczos(rp, ci, 8, np.ones(n))
+    check_leading_coefficients(a, b, a_ref, b_ref, "rccl1 overlapped")
+    check_recurrence(O, rp, ci, a, b, Q, "rccl1 overlapped")
     eng.close()
