@@ -101,7 +101,14 @@ def main():
     desc, kind, scale, n, draws, seed, _ = WORKLOADS[args.workload]
     K, W = args.steps, args.warmup
 
+    # LZX_BENCH_REHEARSE_MULTI=1 (with torch.distributed.run --nproc-per-node 1): the N > 1 flow -- exchange tuning, both
+    # engines, RCCL collectives on the 1-rank communicator -- on a box with one GPU.  A rehearsal of the code path, not
+    # a measurement of anything.
+    rehearse = world == 1 and launched and os.environ.get("LZX_BENCH_REHEARSE_MULTI") == "1"
+
     def make_engine(**options):
+        if rehearse:
+            options = dict(options, exchange_at_world_1=1)
         e = pkg.Engine(local_rank, **options)
         if dist is not None:
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -120,7 +127,7 @@ def main():
     # blocked SpMV.  Which is faster depends on the node's xGMI and on the rank count, so both
     # are timed for a few untimed iterations and every rank adopts the faster one (max over ranks decides).
     tune = {}
-    if world == 1:
+    if world == 1 and not rehearse:
         eng, t_gen = make_engine()
     else:
         def timed(e):

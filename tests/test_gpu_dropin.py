@@ -135,3 +135,22 @@ def test_bench_under_torchrun_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 1 and j["steps"] == 10 and j["value"] > 0
+
+
+def test_bench_rehearses_the_multi_gpu_flow():
+    """The N > 1 flow of bench.py on the one-GPU box: exchange tuning over two engines (single all-gather, two-chunk
+    overlapped exchange), the RCCL collectives on the 1-rank communicator (exchange_at_world_1), rank aggregation."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c2",
+           "--steps", "10", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, LZX_BENCH_REHEARSE_MULTI="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    tune = j["config"]["exchange_tuning_ms_per_iter"]
+    assert set(tune) == {"single", "overlapped"} and min(tune.values()) > 0
+    assert j["value"] > 0 and j["config"]["lanczos_coefficients_finite"]
