@@ -22,6 +22,9 @@ import time
 
 import numpy as np
 
+# multi-process RCCL on this platform needs dmabuf IPC (the host driver has no legacy IPC); must be set before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
