@@ -283,6 +283,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             LZX_HIP(hipSetDevice(c->device));
             const double *uj = first ? c->d_Q : c->d_u[j & 1];   // u_0 = q_0
             SpmvLaunch l{multi ? c->d_xbuf : uj, uj, c->d_v, c->d_partials};
+            l.live_rows_only = true;   // k_lazy_update below takes (A u)_i = 0 for rows without an edge
             if (overlap && j > 0) l.chunk1_ready = c->ev_c1;
             LZX_TRY(lzx_launch_spmv(c, l));
         }
@@ -306,12 +307,12 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             double *p_out = multi ? c->d_partials2 : ((j & 1) ? c->d_partials3 : c->d_partials2);
             const double *p_in = multi ? nullptr : ((j & 1) ? c->d_partials2 : c->d_partials3);
             if (!multi)
-                LZX_TRY(lzx_launch_lazy_update_local(c, c->d_v, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_partials,
+                LZX_TRY(lzx_launch_lazy_update_local(c, c->d_v, c->rows_live, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_partials,
                                                      lzx_spmv_partials(c), p_in, first ? 0 : c->np2_last, first ? 1 : 0, c->d_alpha + j,
                                                      first ? nullptr : c->d_beta + (j - 1), first ? nullptr : c->d_Q + (size_t)j * c->ldq,
                                                      last ? nullptr : c->d_u[(j + 1) & 1], p_out, &np2));
             else
-            LZX_TRY(lzx_launch_lazy_update(c, c->d_v, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_scal + 0, first ? 1 : 0,
+            LZX_TRY(lzx_launch_lazy_update(c, c->d_v, c->rows_live, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_scal + 0, first ? 1 : 0,
                                            c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), first ? nullptr : c->d_Q + (size_t)j * c->ldq,
                                            last ? nullptr : c->d_u[(j + 1) & 1], c->d_partials2, &np2));
             c->np2_last = np2;

@@ -312,6 +312,8 @@ int lzx_graph_prepare(lzx_ctx *c)
         PREP_HIP(e);
         c->max_degree = md;
         c->n_active = h_cnt;
+        const u64 live = h_cnt > rank ? (h_cnt - rank + world - 1) / world : 0;
+        c->rows_live = std::min<u32>(c->n_loc_pad, round_up((u32)live, LZX_SLICE));
     }
     // Only vertices with at least one edge are ever gathered by an SpMV, and (degree-sorted, dealt round-robin)
     // they are a prefix of every rank's slice: the per-iteration exchange moves just that prefix.  (R-MAT: 41 % of

@@ -102,6 +102,7 @@ struct lzx_ctx {
                                        // layout [world][xs0] then [world][xs - xs0] so each chunk is one all-gather and
                                        // the second one can travel while the SpMV already works on the first
     u64 n_active = 0;                  // vertices of degree > 0
+    u32 rows_live = 0;                 // this rank's rows that have an edge (a prefix of its rows), rounded up to whole slices
     u64 xlen = 0;                      // world * xs + LZX_TAIL: length of the vector the SpMV gathers from
     u64 iolen = 0;                     // world * n_loc_pad + LZX_TAIL: full-length layout of hand-over / results
     u64 nnz_local = 0;
@@ -217,14 +218,15 @@ struct SpmvLaunch {
     double *v;             // [n_loc_pad] output
     double *partials;      // block partials of v.q_loc ; count returned by lzx_spmv_partials()
     hipEvent_t chunk1_ready = nullptr;   // overlapped exchange: columns of chunk 1 may be read only after this event
+    bool live_rows_only = false;         // the caller never reads v beyond the rows that have an edge (lzx_ctx::rows_live)
 };
 int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &a);
 u32 lzx_spmv_partials(const lzx_ctx *c);
 int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, int do_sqrt);
 int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, double *out2);
-int lzx_launch_lazy_update(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *scal2, int first,
+int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out);
-int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *pa, u32 na,
+int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,
                                  const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
                                  double *u_next, double *partials_out, u32 *np_out);
 // v -= alpha q_j (+ beta_prev q_jm1); alpha = sum(partials_in); writes alpha_out; partial ||v||^2 out.

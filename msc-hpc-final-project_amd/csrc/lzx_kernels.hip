@@ -376,7 +376,7 @@ k_axpy_norm(double *v, const double *__restrict__ qj, const double *__restrict__
 // first: u_0 = q_0 is already normalised (B := 1).  u_next == nullptr on the last iteration (only q_j is still needed).
 // scal2 == nullptr (one rank): D and B are the fixed-order sums of pa[0..na) and pb[0..nb), closed here by every workgroup.
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
-k_lazy_update(const double *__restrict__ w, const double *__restrict__ u, const double *__restrict__ q_prev,
+k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict__ u, const double *__restrict__ q_prev,
               const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
               double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n)
 {
@@ -406,7 +406,8 @@ k_lazy_update(const double *__restrict__ w, const double *__restrict__ u, const 
         }
         if (q_out) *reinterpret_cast<double2 *>(q_out + i) = q;
         if (u_next) {
-            double2 t = *reinterpret_cast<const double2 *>(w + i);
+            // rows without an edge (the tail beyond w_rows) have (A u)_i = 0: not read, and the SpMV did not write them
+            double2 t = i < w_rows ? *reinterpret_cast<const double2 *>(w + i) : make_double2(0.0, 0.0);
             if (!first) {
                 t.x /= beta;
                 t.y /= beta;
@@ -530,6 +531,8 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.slice_off = c->d_slice_off;
     a.slice_w = c->d_slice_w;
     a.n_slices = (c->phase_mask_opt & 2) ? c->n_slices : 0;
+    if (l.live_rows_only)   // slices of rows without an edge: nothing to sum, and the caller does not read their v
+        a.n_slices = std::min<u32>(a.n_slices, c->rows_live > c->n_long64 ? (c->rows_live - c->n_long64) / LZX_SLICE : 0u);
     a.row0 = c->n_long64;
     a.long_cols = c->d_long_cols;
     a.item_beg = c->d_item_beg;
@@ -597,23 +600,23 @@ int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u
     return LZX_OK;
 }
 
-int lzx_launch_lazy_update(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *scal2, int first,
+int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out)
 {
     const u32 g = vec_grid(c);
-    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
+    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
                        first, alpha_out, beta_out, q_out, u_next, partials_out, c->n_loc_pad);
     LZX_HIP(hipGetLastError());
     *np_out = g;
     return LZX_OK;
 }
 
-int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, const double *u, const double *q_prev, const double *pa, u32 na,
+int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,
                                  const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
                                  double *u_next, double *partials_out, u32 *np_out)
 {
     const u32 g = vec_grid(c);
-    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, u, q_prev, nullptr, pa, na, pb, nb, first,
+    hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, nullptr, pa, na, pb, nb, first,
                        alpha_out, beta_out, q_out, u_next, partials_out, c->n_loc_pad);
     LZX_HIP(hipGetLastError());
     *np_out = g;
