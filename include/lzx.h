@@ -40,15 +40,18 @@ typedef enum lzx_status {
     LZX_ERR_LIMIT = -6   /* size outside what this build supports (nnz per rank >= 2^32) */
 } lzx_status;
 
-/* Timings of the last lzx_lanczos_f64 call (all in milliseconds). */
+/* Timings of the last lzx_lanczos_f64 call (all in milliseconds).  The three per-category sums come from HIP events
+ * recorded on the loop's stream.  Every event is a barrier packet (about 5 us of drained pipeline between two dependent
+ * kernels), so only every 4th iteration carries them (every iteration when k < 8, or with option "timing_marks_every"
+ * = 1) and the sums are scaled to all k iterations. */
 typedef struct lzx_stats {
     double loop_ms;       /* host wall clock around the k-iteration loop, device-synchronised on both
                              sides; excludes upload of x0 and download of alpha/beta/Q              */
     double spmv_ms;       /* sum over iterations of the SpMV(+alpha partial) launches, HIP events on
                              the stream they run on                                                */
     double spmv_ms_min;   /* fastest single iteration's SpMV time                                   */
-    double vec_ms;        /* sum of the axpy+norm and scale launches                                */
-    double comm_ms;       /* sum of the exchange steps (all-reduce x2 + all-gather), 0 at one rank  */
+    double vec_ms;        /* sum of the vector kernel launches (several ranks: + the scalar all-reduce) */
+    double comm_ms;       /* sum of the exposed part of the all-gather(s), 0 at one rank            */
     uint32_t iters;       /* k                                                                      */
     uint32_t spmv_kernels;/* kernel launches counted in spmv_ms per iteration                       */
     uint64_t spmv_bytes;  /* algorithmic bytes of ONE SpMV on this rank:
@@ -179,8 +182,10 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  *                           beta come out of one reduction per iteration (one 2-double all-reduce) and one vector kernel;
  *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on
  *                           one GPU in plain mode
- *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "pb_column_band", "side_stream", "exchange_at_world_1"
- *                           experiment knobs behind DESIGN.md's tuning log (tools/perf_probe.py)               */
+ *   "timing_marks_every"    iterations between the HIP-event timing marks behind lzx_stats (default 4; 1 = every iteration)
+ *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit",
+ *   "pb_column_band", "side_stream", "exchange_at_world_1"
+ *                           experiment knobs and test hooks behind DESIGN.md's tuning log (tools/perf_probe.py)    */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -108,6 +108,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
+    else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
@@ -183,8 +184,17 @@ struct Marks {
     lzx_ctx *c;
     size_t used = 0;
     std::vector<int> cat;
+    bool on = true;   // every mark is a barrier packet (~5 us of drained pipeline): only every few iterations carry marks
+    u32 sampled = 0;  // iterations that carried marks
+    int begin_iteration(u32 j, u32 every)
+    {
+        on = every <= 1 || j % every == 0;
+        if (on) ++sampled;
+        return tick(CAT_NONE);   // what ran since the last marked iteration is billed to nobody
+    }
     int tick(int category)
     {
+        if (!on) return LZX_OK;
         LZX_HIP(hipSetDevice(c->device));
         if (used == c->ev_pool.size()) {
             hipEvent_t ev;
@@ -270,8 +280,11 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     // One rank in blocked mode (whose sums are already ordered differently from the reference's) takes the same form:
     // it saves k_scale's pass over v and a launch; in plain mode one rank keeps the reference's order bit for bit.
     const bool lazy = c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (multi || c0->codes16));
+    // timing marks on every 4th iteration (every one when k is small); the sums below are scaled to all k
+    const u32 every = c0->marks_every_opt > 0 ? (u32)c0->marks_every_opt : (k >= 8 ? 4u : 1u);
     for (u32 j = 0; lazy && j < k; ++j) {
         const bool first = j == 0, last = j == k - 1;
+        LZX_TRY(mk.begin_iteration(j, every));
         if (overlap && j > 0) {
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
@@ -349,6 +362,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         }
     }
     for (u32 j = 0; !lazy && j < k; ++j) {
+        LZX_TRY(mk.begin_iteration(j, every));
         // v = A q_j ; partials of alpha_j
         if (overlap && j > 0) {
             // chunk 0 of q_j (the high-degree end of every slice, where the staged hub entries and nearly all
@@ -448,6 +462,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             }
         }
     }
+    mk.on = true;
     LZX_TRY(sync_all(cs));
     const auto t1 = std::chrono::steady_clock::now();
     for (lzx_ctx *c : cs) { c->k_last = k; c->k_prep = 0; }
@@ -456,7 +471,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         memset(stats, 0, sizeof *stats);
         stats->loop_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats->iters = k;
-        stats->spmv_kernels = 1 + (c0->fin_grid > 0 ? 1 : 0) + (c0->pb ? 2 + (c0->pb_finish_grid ? 1 : 0) : 0);
+        stats->spmv_kernels = c0->pb ? 3 + (c0->pb_finish_grid ? 1 : 0) : 1 + (c0->fin_grid > 0 ? 1 : 0);
         stats->spmv_bytes = spmv_algorithmic_bytes(c0);
         stats->spmv_ms_min = 1e300;
         for (size_t i = 1; i < mk.used; ++i) {
@@ -470,6 +485,12 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             }
         }
         if (stats->spmv_ms_min == 1e300) stats->spmv_ms_min = 0.0;
+        if (mk.sampled > 0 && mk.sampled < k) {   // marks were carried by `sampled` of the k iterations: scale the sums
+            const double f = (double)k / (double)mk.sampled;
+            stats->spmv_ms *= f;
+            stats->vec_ms *= f;
+            stats->comm_ms *= f;
+        }
     }
     return LZX_OK;
 }

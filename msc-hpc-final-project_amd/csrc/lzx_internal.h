@@ -117,6 +117,7 @@ struct lzx_ctx {
     u32 pb_units0 = 0;                 // scatter units whose column band lies wholly in chunk 0
     int64_t pb_target_opt = -1;        // entries per row band override
     int64_t pb_align_opt = -1;         // run padding override (4, 8, 16)
+    int64_t marks_every_opt = -1;      // iterations between timing marks in the Lanczos loop (-1: 4, or 1 for short runs)
     bool force_multi = false;          // test hook: a 1-rank RCCL communicator runs the several-rank code path, collectives included
     int64_t lazy_opt = -1;             // lazy normalisation (lzx_api.hip): -1 = with several ranks and in blocked mode, 0 off, 1 on
     int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
