@@ -251,3 +251,27 @@ def test_rccl_world1(oracle, pkg):
     check_leading_coefficients(a, b, a_ref, b_ref, "rccl1 overlapped")
     check_recurrence(O, rp, ci, a, b, Q, "rccl1 overlapped")
     eng.close()
+
+
+def test_general_csr_patterns(oracle, engine_factory):
+    """The C ABI takes any pattern-only CSR, not only what the reference's loader produces: non-symmetric, columns in
+    any order, duplicate entries (each one counts), self-loops, empty rows -- plain and blocked SpMV agree with the
+    row sums of the oracle."""
+    O = oracle
+    rng = np.random.default_rng(11)
+    n = 70000
+    deg = rng.integers(0, 40, size=n)
+    deg[rng.integers(0, n, size=50)] = 3000            # a few long rows
+    deg[:10] = 0                                       # leading empty rows
+    rp = np.zeros(n + 1, dtype=np.uint64)
+    rp[1:] = np.cumsum(deg)
+    ci = rng.integers(0, n, size=int(rp[-1]), dtype=np.uint32)   # unsorted, with duplicates and self-loops
+    ci[: int(rp[20])] = np.arange(int(rp[20]), dtype=np.uint32) % 7   # heavy duplication in the first rows
+    x = rng.random(n)
+    y_ref = O.spmv(rp, ci, x)
+    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=1024),
+                 dict(propagation_blocking=1, hub_entries=1024, pb_reduce=0)):
+        eng = engine_factory(**mode)
+        eng.set_graph_csr(rp, ci)
+        assert np.allclose(eng.spmv(x), y_ref, rtol=1e-12, atol=1e-12), mode
+        eng.close()
