@@ -183,7 +183,7 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on
  *                           one GPU in plain mode
  *   "timing_marks_every"    iterations between the HIP-event timing marks behind lzx_stats (default 4; 1 = every iteration)
- *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit",
+ *   "wgs_per_cu", "nt_index_loads", "long_row", "phase_mask", "pb_target", "pb_run_align", "pb_reduce", "pb_unit", "pb_taper",
  *   "pb_column_band", "side_stream", "exchange_at_world_1"
  *                           experiment knobs and test hooks behind DESIGN.md's tuning log (tools/perf_probe.py)    */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);

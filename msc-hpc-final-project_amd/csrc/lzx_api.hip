@@ -104,6 +104,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "pb_reduce")) c->pb_reduce_opt = value;
     else if (!strcmp(name, "pb_unit")) c->pb_unit_opt = value;
+    else if (!strcmp(name, "pb_taper")) c->pb_taper_opt = value;
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;

@@ -123,6 +123,7 @@ struct lzx_ctx {
     int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
     int64_t pb_cb_opt = -1;            // column band override (8192 or 16384)
     u32 pb_cb = LZX_PB_CB;             // x values per column band = per LDS tile of the scatter pass
+    int64_t pb_taper_opt = -1;         // tapered scatter unit sizes: -1/1 on, 0 off
     int64_t pb_unit_opt = -1;          // entries per scatter unit override
     int64_t pb_reduce_opt = -1;        // reduced bands: -1 auto (on), 0 off, > 1: minimum average run length
     int64_t long_row_opt = -1;         // split-row threshold override

@@ -63,6 +63,8 @@ if __name__ == "__main__":
         opts = [dict(), dict(long_row=256), dict(long_row=512), dict(long_row=1024), dict(long_row=2048), dict(long_row=256)]
     if "unit" in sets:
         opts = [dict(), dict(pb_unit=131072), dict(pb_unit=262144), dict(), dict(pb_unit=131072), dict(pb_unit=262144), dict(pb_unit=32768)]
+    if "taper" in sets:
+        opts = [dict(), dict(pb_taper=0), dict(), dict(pb_taper=0)]
     if "one" in sets:
         opts = [dict(pb_reduce=0)]
     if "phase" in sets:

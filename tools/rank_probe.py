@@ -14,7 +14,7 @@ src.gen_rmat(scale, n, draws, 1234)
 rp, ci = src.get_graph_csr()
 src.close()
 for world in (2, 4, 8):
-    for opts in (dict(), dict(pb_unit=65536), dict(), dict(pb_unit=65536)):
+    for opts in (dict(), dict(pb_taper=1), dict(), dict(pb_taper=1)):
         if world == 1:
             eng = pkg.Engine(0, **opts)
             eng.set_graph_csr(rp, ci)
