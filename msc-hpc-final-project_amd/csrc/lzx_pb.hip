@@ -496,6 +496,9 @@ __device__ __forceinline__ double wave_sum_pb(double v)
 // item table entry: {row band, begin, end, slot} in gather positions; slot == 0xffffffff: the item is its band's
 // only one and adds straight into v; otherwise it is one of several items of its band and leaves its per-row totals
 // in part[slot + row in band] for k_pb_finish.
+// One WORKGROUP per item: its eight wavefronts take the item's 128-value blocks round-robin (so the workgroup reads 8
+// consecutive KiB at a time -- a few hundred sequential streams chip-wide instead of four thousand), each adding into
+// its own y tile; the tiles are folded in wavefront order.
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
 k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *band_rep, const uint16_t *lslot,
             const double *val, double *v, const double *__restrict__ q_loc, double *part, double *partials)
@@ -503,53 +506,60 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
     constexpr u32 TILE = LZX_PB_RB + 8;                  // + spare slot for padding entries
-    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     double *ytile = lds + (size_t)wv * TILE;             // private to this wavefront
-    double *wsum = lds + (size_t)WAVES * TILE;
-    const u32 waves = gridDim.x * WAVES;
+    double *wsum = lds + (size_t)WAVES * TILE;           // [WAVES]
     double dot = 0.0;
-    for (u32 it = blockIdx.x * WAVES + wv; it < n_items; it += waves) {
+    for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const uint4 item = items[it];
         const u32 R = item.x, beg = item.y, end = item.z;
         const u32 row0 = band_row0[R], rows = band_row0[R + 1] - row0;
         if (rows == 1) {
-            // one heavy row: plain strided sum (padding holds zeros), fixed butterfly
+            // one heavy row: plain strided sum (padding holds zeros), fixed reduction order
             double acc = 0.0;
-            u32 i = beg + lane;
-            for (; i + 7 * 64 < end; i += 8 * 64) {
+            u32 i = beg + tid;
+            for (; i + 7 * LZX_PB_GATHER_BLOCK < end; i += 8 * LZX_PB_GATHER_BLOCK) {
                 double a[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] = val[i + u * 64];
+                for (int u = 0; u < 8; ++u) a[u] = val[i + u * LZX_PB_GATHER_BLOCK];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += a[u];
             }
-            for (; i < end; i += 64) acc += val[i];
+            for (; i < end; i += LZX_PB_GATHER_BLOCK) acc += val[i];
             acc = wave_sum_pb(acc);
-            if (lane == 0) {
+            __syncthreads();                 // wsum free
+            if (lane == 0) wsum[wv] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (u32 w = 0; w < WAVES; ++w) t += wsum[w];
                 if (item.w == 0xffffffffu) {
-                    v[row0] += acc;
-                    dot += acc * q_loc[row0];
+                    v[row0] += t;
+                    dot += t * q_loc[row0];
                 } else {
-                    part[item.w] = acc;
+                    part[item.w] = t;
                 }
             }
             continue;
         }
         const u32 rep = band_rep[R];
         const u32 slots = rows * rep;
+        __syncthreads();                     // the previous item's fold is done with the tiles
         for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
         __builtin_amdgcn_wave_barrier();
-        // whole blocks of 128 values (an item begins on a block boundary of its band): lane l owns values 2 l, 2 l + 1;
-        // eight blocks in flight
-        const u32 blocks_end = beg + ((end - beg) / 128u) * 128u;
-        u32 b = beg;
-        for (; b + 8 * 128 <= blocks_end; b += 8 * 128) {
+        // whole blocks of 128 values (an item begins on a block boundary of its band): lane l owns values 2 l, 2 l + 1
+        // of its wavefront's blocks; eight blocks in flight per wavefront
+        const u32 blocks = (end - beg) / 128u;
+        u32 kb = wv;
+        for (; kb + 7 * WAVES < blocks; kb += 8 * WAVES) {
             double2 av[8];
             u32 sv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                av[u] = *reinterpret_cast<const double2 *>(val + b + u * 128 + lane * 2);
-                sv[u] = *reinterpret_cast<const u32 *>(lslot + b + u * 128 + lane * 2);
+                const u32 p = beg + (kb + u * WAVES) * 128u + lane * 2;
+                av[u] = *reinterpret_cast<const double2 *>(val + p);
+                sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -557,50 +567,53 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
                 atomicAdd(&ytile[sv[u] >> 16], av[u].y);
             }
         }
-        for (; b < blocks_end; b += 128) {
-            const double2 a = *reinterpret_cast<const double2 *>(val + b + lane * 2);
-            const u32 s = *reinterpret_cast<const u32 *>(lslot + b + lane * 2);
+        for (; kb < blocks; kb += WAVES) {
+            const u32 p = beg + kb * 128u + lane * 2;
+            const double2 a = *reinterpret_cast<const double2 *>(val + p);
+            const u32 s = *reinterpret_cast<const u32 *>(lslot + p);
             atomicAdd(&ytile[s & 0xffffu], a.x);
             atomicAdd(&ytile[s >> 16], a.y);
         }
-        // the band's tail: 64 consecutive values per instruction
-        for (u32 i = blocks_end + lane; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
-        __builtin_amdgcn_wave_barrier();
+        // the band's tail (< 128 values): 64 consecutive values per instruction, wavefront 0
+        if (wv == 0)
+            for (u32 i = beg + blocks * 128u + lane; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
+        __syncthreads();
+        // fold: wavefront tiles in order, replicas in order; every thread a few rows, loads before stores
         if (item.w == 0xffffffffu) {
-            // fold into v: eight rows per lane at a time, all their v and q loads in flight before the first store
-            // (row by row this was a chain of up to 16 dependent memory round trips per item)
-            for (u32 j0 = lane; j0 < rows; j0 += 8 * 64) {
-                double vv[8], qq[8];
+            for (u32 j0 = tid; j0 < rows; j0 += 2 * LZX_PB_GATHER_BLOCK) {
+                double vv[2], qq[2];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const u32 j = j0 + u * 64;
+                for (int u = 0; u < 2; ++u) {
+                    const u32 j = j0 + u * LZX_PB_GATHER_BLOCK;
                     vv[u] = j < rows ? v[row0 + j] : 0.0;
                     qq[u] = j < rows ? q_loc[row0 + j] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const u32 j = j0 + u * 64;
+                for (int u = 0; u < 2; ++u) {
+                    const u32 j = j0 + u * LZX_PB_GATHER_BLOCK;
                     if (j < rows) {
                         double y = 0.0;
-                        for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                        for (u32 w = 0; w < WAVES; ++w)
+                            for (u32 t = 0; t < rep; ++t) y += lds[(size_t)w * TILE + j * rep + t];
                         v[row0 + j] = vv[u] + y;
                         dot += y * qq[u];
                     }
                 }
             }
         } else {
-            for (u32 j = lane; j < rows; j += 64) {
+            for (u32 j = tid; j < rows; j += LZX_PB_GATHER_BLOCK) {
                 double y = 0.0;
-                for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                for (u32 w = 0; w < WAVES; ++w)
+                    for (u32 t = 0; t < rep; ++t) y += lds[(size_t)w * TILE + j * rep + t];
                 part[item.w + j] = y;
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
     dot = wave_sum_pb(dot);
+    __syncthreads();
     if (lane == 0) wsum[wv] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double s = 0.0;
         for (u32 i = 0; i < WAVES; ++i) s += wsum[i];
         partials[blockIdx.x] = s;
@@ -808,8 +821,9 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     // CU) should get a few items, and an item should not be shorter than its fold is worth
     u32 target = LZX_PB_TARGET;
     {
-        const u64 want = total / ((u64)c->cu_count * 32);
-        target = (u32)std::min<u64>(LZX_PB_TARGET, std::max<u64>(4096, (want + 1023) & ~1023ull));
+        // a workgroup (8 wavefronts) per item, two workgroups per CU, a few items each
+        const u64 want = total / ((u64)c->cu_count * 8);
+        target = (u32)std::min<u64>(8 * LZX_PB_TARGET, std::max<u64>(8192, (want + 1023) & ~1023ull));
     }
     if (c->pb_target_opt > 0) target = (u32)c->pb_target_opt;
     // entries per scatter unit: every unit restages its column band while its CU does nothing else, and a workgroup
@@ -1110,7 +1124,8 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     c->pb_values = len;
     c->pb_nr = nr;
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
-    c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2, std::max(1u, (c->pb_n_items + waves_per_wg - 1) / waves_per_wg));
+    (void)waves_per_wg;
+    c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2, std::max(1u, c->pb_n_items));   // one item per workgroup at a time
     c->pb_finish_grid = (c->pb_n_multi + c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;   // + the split rows of k_spmv
     return LZX_OK;
 }
