@@ -22,13 +22,14 @@
 //       columns-in-band, one 4-byte load of the quad's value slot), looks the four values up and writes them with
 //       two 16-byte stores (padding reads a zero kept behind the staged band).
 //     Value slots are in gather order, so a run is one contiguous, 64-byte aligned stretch of writes.
-//   gather (k_pb_gather): a row band's values are cut into items of ~16 Ki values; one wavefront streams an item's
-//     values + 2-byte LDS slots and adds each value into a wave-private LDS y tile with ds_add_f64.  The slot of a
-//     value is row * rep + replica, the replica chosen when the graph is reshaped so that the 64 lanes of one step
-//     (almost) never share a slot: no shuffles, no serialised conflicts; only this wavefront touches the tile, so
-//     additions happen in program order.  The tile is then folded (rep replicas per row) and added to v (the band's
-//     only item) or left as per-row totals that k_pb_finish adds in item order; the wave forms its share of
-//     alpha = v . q.
+//   gather (k_pb_gather): a row band's values are cut into items of up to ~256 Ki values; one WORKGROUP per item, its
+//     eight wavefronts taking the item's 128-value blocks round-robin (the workgroup streams 8 consecutive KiB of
+//     values + 2-byte LDS slots at a time) and adding each value into a wave-private LDS y tile with ds_add_f64.  The
+//     slot of a value is row * rep + replica, the replica chosen when the graph is reshaped so that the 64 lanes of one
+//     instruction (almost) never share a slot: no shuffles, no serialised conflicts; only its own wavefront touches a
+//     tile, so additions happen in program order.  The eight tiles are then folded in wavefront order (rep replicas
+//     per row) and added to v (the band's only item) or left as per-row totals that k_pb_finish adds in item order; the
+//     workgroup forms its share of alpha = v . q.
 // All tables are static (built once per graph by lzx_pb_prepare: radix sorts and a few scans, on the device).
 #include <hipcub/hipcub.hpp>
 

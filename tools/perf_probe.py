@@ -56,7 +56,7 @@ if __name__ == "__main__":
     if "tune2" in sets:
         opts = [dict(), dict(pb_target=4096), dict(pb_target=8192), dict(pb_target=32768), dict(pb_reduce=128), dict(pb_reduce=192), dict(pb_reduce=256), dict()]
     if "tgt" in sets:
-        opts = [dict(), dict(pb_target=4096), dict(pb_target=6144), dict(pb_target=8192), dict(pb_target=12288), dict(pb_target=2048)]
+        opts = [dict(), dict(pb_target=32768), dict(pb_target=65536), dict(pb_target=262144), dict(), dict(pb_target=65536)]
     if "iso" in sets:
         opts = [dict(), dict(phase_mask=3 + 4), dict(phase_mask=3 + 8), dict()]
     if "lr" in sets:
