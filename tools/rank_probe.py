@@ -13,8 +13,8 @@ src = pkg.Engine(0, propagation_blocking=0)
 src.gen_rmat(scale, n, draws, 1234)
 rp, ci = src.get_graph_csr()
 src.close()
-for world in (2, 4, 8):
-    for opts in (dict(), dict(pb_taper=1), dict(), dict(pb_taper=1)):
+for world in (1, 2, 4, 8):
+    for opts in (dict(propagation_blocking=0), dict()):
         if world == 1:
             eng = pkg.Engine(0, **opts)
             eng.set_graph_csr(rp, ci)
