@@ -10,7 +10,7 @@ import __graft_entry__ as ge
 
 pkg = ge.load_pkg()
 WORK = {"c2": (20, 1 << 20, 20_000_000), "c3": (24, 10_000_000, 200_000_000), "c2b": (20, 1_000_000, 20_000_000),
-        "big": (25, 30_000_000, 600_000_000)}
+        "big": (25, 30_000_000, 600_000_000), "c5": (27, 100_000_000, 2_000_000_000)}
 
 
 def run(name, opts_list, k=20):
@@ -65,6 +65,8 @@ if __name__ == "__main__":
         opts = [dict(), dict(pb_unit=131072), dict(pb_unit=262144), dict(), dict(pb_unit=131072), dict(pb_unit=262144), dict(pb_unit=32768)]
     if "taper" in sets:
         opts = [dict(), dict(pb_taper=0), dict(), dict(pb_taper=0)]
+    if "c5x" in sets:
+        opts = [dict(), dict(pb_taper=0), dict(pb_target=65536), dict(pb_target=32768), dict(long_row=128)]
     if "one" in sets:
         opts = [dict(pb_reduce=0)]
     if "phase" in sets:
