@@ -444,10 +444,11 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
 
     {   // ---- plain bands
         const u32 beg = unit[5 * blockIdx.x + 3], end = unit[5 * blockIdx.x + 4];
-        const u32 span = (((end - beg) + W - 1) / W + 63u) & ~63u;   // quads per wavefront, multiple of 64
-        const u32 wbeg = beg + wv * span;
-        const u32 wend = wbeg + span < end ? wbeg + span : end;
-        u32 j = wbeg + lane;
+        // wavefront w takes the unit's 256-quad blocks w, w + 16, ...: the workgroup reads one stream and its writes
+        // move through the value array together
+        for (u32 blk = beg + wv * 256u; blk < end; blk += W * 256u) {
+        const u32 wend = blk + 256u < end ? blk + 256u : end;
+        u32 j = blk + lane;
         for (; j + 3 * 64 < wend; j += 4 * 64) {
             uint2 c[4];
             u32 d[4];
@@ -483,6 +484,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
             double2 *out = reinterpret_cast<double2 *>(val + q_dst[j]);
             out[0] = lo;
             out[1] = hi;
+        }
         }
     }
 }
