@@ -233,7 +233,11 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     for (lzx_ctx *c : cs) {
         LZX_TRY(ensure_capacity(c, k));
         c->k_last = 0;
-        LZX_HIP(hipMemsetAsync(c->d_Q, 0, sizeof(double) * (size_t)k * c->ldq, c->stream));
+        // column 0 (its padded rows must be 0) and the zero tail behind every column; columns 1.. are written whole by
+        // the loop (clearing all k columns cost 4 GB of memset at C3)
+        LZX_HIP(hipMemsetAsync(c->d_Q, 0, sizeof(double) * c->ldq, c->stream));
+        if (k > 1)
+            LZX_HIP(hipMemset2DAsync(c->d_Q + c->ldq + c->n_loc_pad, sizeof(double) * c->ldq, 0, sizeof(double) * LZX_TAIL, k - 1, c->stream));
         LZX_HIP(hipMemcpyAsync(c->d_io, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
         // q_0 = x0 / ||x0|| (serial/lib/lanczos.cc:16-17), scattered into the internal order
         if (!multi) {
