@@ -1149,7 +1149,12 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
                   hipEvent_t v_ready)
 {
-    if (!c->pb) return LZX_OK;
+    if (!c->pb) {
+        // no blocked tables on this rank: still order the stream behind the second chunk of the exchange, so that the next
+        // collective on the main stream never starts while that all-gather is in flight on the exchange stream
+        if (chunk1_ready) LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
+        return LZX_OK;
+    }
     const size_t lds1 = ((size_t)c->pb_cb + 2 + 16 * 66) * sizeof(double);
     static const int ablate = getenv("LZX_ABLATE") ? atoi(getenv("LZX_ABLATE")) : 0;
     auto kern = c->pb_cb == 8192 ? (ablate ? k_pb_scatter<8192, true> : k_pb_scatter<8192, false>)
