@@ -206,6 +206,7 @@ def main():
     t_out = time.perf_counter() - t_out
     finite = bool(np.isfinite(alpha).all() and np.isfinite(beta).all())
 
+    stream = eng.bench_stream(1 << 30, 5) if rank == 0 else (0.0, 0.0)
     if rank == 0:
         spmv_avg_ms = spmv_ms_max / K
         achieved = spmv_bytes_total / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
@@ -250,6 +251,9 @@ def main():
                 "frac": achieved / (HBM_PEAK_GBS * world),
                 "traffic": pmc_traffic(args.workload, world)[0],
                 "traffic_source": pmc_traffic(args.workload, world)[1],
+                # the same box's own streaming rates (read-only sum / copy over 1 GiB, rank 0) and the SpMV against them
+                "measured_stream_read_GBps": stream[0], "measured_stream_copy_GBps": stream[1],
+                "frac_of_measured_stream_read": achieved / (stream[0] * world) if stream[0] else None,
                 "algorithmic_bytes_per_spmv": spmv_bytes_total,
                 "avg_spmv_ms": spmv_avg_ms,
                 "spmv_share_of_loop": spmv_ms_max / (elapsed * 1e3),

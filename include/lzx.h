@@ -171,6 +171,11 @@ int lzx_multout_f64_local(lzx_handle *hs, int world, const double *t, uint32_t k
  * average and minimum HIP-event time of one SpMV (all its kernels) in milliseconds.              */
 int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
 
+/* Measurement hook (no reference counterpart): the device's own streaming rates, for the roofline's "fraction of a
+ * measured STREAM kernel on the same box" (SURVEY.md 8(d)): a read-only sum and a copy over a scratch buffer of `bytes`
+ * bytes (rounded to 16; >= 256 MiB recommended), best of `reps`.  Results in GB/s (copy: bytes read + bytes written). */
+int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_gbs, double *copy_gbs);
+
 /* Tuning knobs, to be set before the graph is handed over:
  *   "hub_entries"           x values of the highest-degree vertices staged in LDS by the SpMV (0 = none)
  *   "propagation_blocking"  1 / 0 force the two-pass blocked treatment of non-staged columns on / off

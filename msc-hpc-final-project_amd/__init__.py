@@ -73,6 +73,7 @@ SYMBOLS = [
     ("lzx_multout_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
     ("lzx_multout_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p]),
     ("lzx_bench_spmv", ctypes.c_int, [_h, ctypes.c_uint32, _f64p, _f64p]),
+    ("lzx_bench_stream", ctypes.c_int, [_h, ctypes.c_uint64, ctypes.c_uint32, _f64p, _f64p]),
     ("lzx_set_option", ctypes.c_int, [_h, ctypes.c_char_p, ctypes.c_int64]),
 ]
 
@@ -243,6 +244,11 @@ class Engine:
         ans = np.empty(self.n)
         _check(lib().lzx_multout_f64(self.h, _p(t, _f64p), len(t), _p(ans, _f64p)), "lzx_multout_f64")
         return ans
+
+    def bench_stream(self, nbytes: int = 1 << 30, reps: int = 5):
+        rd, cp = ctypes.c_double(), ctypes.c_double()
+        _check(lib().lzx_bench_stream(self.h, nbytes, reps, ctypes.byref(rd), ctypes.byref(cp)), "lzx_bench_stream")
+        return rd.value, cp.value
 
     def bench_spmv(self, reps: int = 20):
         avg, mn = ctypes.c_double(), ctypes.c_double()

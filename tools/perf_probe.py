@@ -69,6 +69,8 @@ if __name__ == "__main__":
         opts = [dict(), dict(pb_taper=0), dict(pb_target=65536), dict(pb_target=32768), dict(long_row=128)]
     if "hubph" in sets:
         opts = [dict(), dict(phase_mask=1), dict(phase_mask=2), dict(long_row=512), dict(long_row=512, phase_mask=1), dict(long_row=512, phase_mask=2)]
+    if "minrun" in sets:
+        opts = [dict(), dict(pb_reduce=256), dict(pb_reduce=192), dict(pb_reduce=512), dict(), dict(pb_reduce=256)]
     if "one" in sets:
         opts = [dict(pb_reduce=0)]
     if "phase" in sets:
