@@ -86,9 +86,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start one rank per GPU as CHILD processes (nothing has touched the GPU
+        # yet, and nothing is exec'ed from a GPU process) and relay rank 0's JSON line and the return code
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        sys.stdout.write(child.stdout)
+        sys.stdout.flush()
+        sys.exit(child.returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     import torch  # device plumbing + torch.distributed only
@@ -109,10 +121,29 @@ def main():
     # a measurement of anything.
     rehearse = world == 1 and launched and os.environ.get("LZX_BENCH_REHEARSE_MULTI") == "1"
 
+    def all_ok(ok: bool) -> bool:
+        """Every rank learns whether a LOCAL step failed anywhere, before anybody enters the next collective."""
+        if dist is None:
+            return ok
+        flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return flag.item() == 0.0
+
     def make_engine(**options):
+        """(engine, seconds of graph build), or (None, 0) on EVERY rank when a local step failed on any of them.
+        Local steps (handle creation, graph generation + reshaping) are guarded and agreed on with an all-reduce;
+        the collective ones (id broadcast, ncclCommInitRank) run outside any try: an error there is fatal anyway."""
         if rehearse:
             options = dict(options, exchange_at_world_1=1)
-        e = pkg.Engine(local_rank, **options)
+        e = None
+        try:
+            e = pkg.Engine(local_rank, **options)
+        except Exception as exc:
+            print(f"[bench rank {rank}] engine: {exc}", file=sys.stderr, flush=True)
+        if not all_ok(e is not None):
+            if e is not None:
+                e.close()
+            return None, 0.0
         if dist is not None:
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
@@ -120,10 +151,18 @@ def main():
             dist.broadcast(uid, 0)
             e.comm_init_rank(uid.cpu().numpy(), rank, world)
         t = time.perf_counter()
-        if kind == "er":
-            e.gen_er(n, draws, seed)
-        else:
-            e.gen_rmat(scale, n, draws, seed)
+        ok = True
+        try:
+            if kind == "er":
+                e.gen_er(n, draws, seed)
+            else:
+                e.gen_rmat(scale, n, draws, seed)
+        except Exception as exc:
+            print(f"[bench rank {rank}] graph: {exc}", file=sys.stderr, flush=True)
+            ok = False
+        if not all_ok(ok):
+            e.close()
+            return None, 0.0
         return e, time.perf_counter() - t
 
     # Several ranks: the exchange can run as one all-gather before a plain SpMV, or as two chunks overlapping the
@@ -132,6 +171,8 @@ def main():
     tune = {}
     if world == 1 and not rehearse:
         eng, t_gen = make_engine()
+        if eng is None:
+            sys.exit("bench.py: could not build the engine")
     else:
         def timed(e):
             best = float("inf")
@@ -147,18 +188,12 @@ def main():
             return best / 6 * 1e3
 
         eng, t_gen = make_engine(overlap_exchange=0)
+        if eng is None:
+            sys.exit(f"bench.py rank {rank}: could not build the engine (see stderr of the failing rank)")
         tune["single"] = timed(eng)
-        alt, failed = None, 0.0
-        try:
-            alt, _ = make_engine()
-            if not alt.info()["pb_entries"]:
-                failed = 1.0       # this rank count / graph does not qualify for the overlapped mode: nothing to compare
-        except Exception as exc:   # an error (not a hang) on any rank sends everybody back to the single all-gather
-            print(f"[bench rank {rank}] overlapped exchange unavailable: {exc}", file=sys.stderr, flush=True)
-            failed = 1.0
-        flag = torch.tensor([failed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if flag.item() == 0.0:
+        alt, _ = make_engine()
+        # a rank count / graph that does not qualify for the overlapped mode on some rank: nothing to compare
+        if alt is not None and all_ok(bool(alt.info()["pb_entries"])):
             tune["overlapped"] = timed(alt)
             if tune["overlapped"] < tune["single"]:
                 eng.close()

@@ -84,6 +84,10 @@ typedef struct lzx_graph_info {
  * cu_decompose (parallel-final/lib/cu_lanczos.cu:37-86); unlike it, failure leaves nothing
  * half-built.                                                                                    */
 int lzx_create(lzx_handle *out, int device_id);
+/* GPUs visible to this process (0 when there is no usable device: never an error).  The drop-in classes use it to
+ * decide between the device ingest and the host loader and to spread a decomposition over several cards, as
+ * parallel-two-cards drives its two from one process (parallel-two-cards/lib/cu_lanczos.cu:73-190). */
+int lzx_device_count(int *count);
 void lzx_destroy(lzx_handle h);
 const char *lzx_last_error(void);
 
@@ -111,9 +115,9 @@ int lzx_set_graph_csr32(lzx_handle h, uint32_t n, uint32_t nnz, const uint32_t *
                         const uint32_t *col_idx);
 
 /* Device-side ingest: `m` undirected edges as 0-based endpoint pairs, in any
- * order, duplicates and self loops allowed; symmetrised, sorted and de-duplicated on the GPU into
- * the CSR that adjMatrix::populate_sparse_matrix builds with a std::set
- * (parallel-final/lib/adjMatrix.cc:21-46).                                                        */
+ * order, duplicates allowed; symmetrised, sorted and de-duplicated on the GPU into the CSR that
+ * adjMatrix::populate_sparse_matrix builds with a std::set (parallel-final/lib/adjMatrix.cc:21-46):
+ * a self loop becomes one diagonal entry, as it does there.  Endpoints >= n are an LZX_ERR_ARG.   */
 int lzx_set_graph_edges(lzx_handle h, uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst);
 
 /* Seeded synthetic graphs generated on the GPU (the reference's generators are seeded from
@@ -153,6 +157,7 @@ int lzx_lanczos_f64(lzx_handle h, const double *x0, uint32_t k, double *alpha, d
 int lzx_lanczos_prepare_f64(lzx_handle h, const double *x0, uint32_t k, double *x_norm);
 int lzx_lanczos_run(lzx_handle h, lzx_stats *stats);
 int lzx_lanczos_fetch_f64(lzx_handle h, uint32_t k, double *alpha, double *beta, double *Q);
+int lzx_lanczos_fetch_f64_local(lzx_handle *hs, int world, uint32_t k, double *alpha, double *beta, double *Q);
 /* Wait for everything queued on the handle's stream. */
 int lzx_sync(lzx_handle h);
 /* The same over `world` handles wired with lzx_comm_init_local, driven by one host thread. */

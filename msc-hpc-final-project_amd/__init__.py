@@ -69,6 +69,8 @@ SYMBOLS = [
     ("lzx_lanczos_prepare_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
     ("lzx_lanczos_run", ctypes.c_int, [_h, ctypes.POINTER(LzxStats)]),
     ("lzx_lanczos_fetch_f64", ctypes.c_int, [_h, ctypes.c_uint32, _f64p, _f64p, _f64p]),
+    ("lzx_lanczos_fetch_f64_local", ctypes.c_int, [_hp, ctypes.c_int, ctypes.c_uint32, _f64p, _f64p, _f64p]),
+    ("lzx_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ("lzx_sync", ctypes.c_int, [_h]),
     ("lzx_multout_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
     ("lzx_multout_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p]),

@@ -107,6 +107,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_taper")) c->pb_taper_opt = value;
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
+    else if (!strcmp(name, "pb_persistent")) c->pb_persist_opt = value;
     else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
@@ -263,7 +264,8 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     lzx_ctx *c0 = cs[0];
     const u32 k = c0->k_prep;
     for (lzx_ctx *c : cs)
-        if (c->k_prep == 0 || c->k_prep != k) LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_run: no prepared start vector");
+        if (c->k_prep == 0 || c->k_prep != k || !c->d_Q || c->q_cols < k)
+            LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_run: no prepared start vector (prepare, then run, with no other call on the handle between them)");
     const bool multi = lzx_exchanges(c0);
     LZX_TRY(sync_all(cs));
 
@@ -572,6 +574,22 @@ extern "C" int lzx_lanczos_fetch_f64(lzx_handle h, uint32_t k, double *alpha, do
     return lanczos_fetch(cs, k, alpha, beta, Q);
 }
 
+extern "C" int lzx_lanczos_fetch_f64_local(lzx_handle *hs, int world, uint32_t k, double *alpha, double *beta, double *Q)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles_local(hs, world, cs));
+    return lanczos_fetch(cs, k, alpha, beta, Q);
+}
+
+extern "C" int lzx_device_count(int *count)
+{
+    if (!count) LZX_FAIL(LZX_ERR_ARG, "lzx_device_count: null pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;   // no driver / no GPU: zero devices, not an error
+    *count = n;
+    return LZX_OK;
+}
+
 extern "C" int lzx_sync(lzx_handle h)
 {
     if (!h) LZX_FAIL(LZX_ERR_ARG, "lzx_sync: null handle");
@@ -597,6 +615,8 @@ static int spmv_run(std::vector<lzx_ctx *> &cs, const double *x, double *y)
     const bool multi = lzx_exchanges(c0);
     std::vector<const double *> src(cs.size());
     std::vector<double *> dst(cs.size());
+    // this call overwrites the work vectors a prepared decomposition keeps its start vector in: the preparation is void
+    for (lzx_ctx *c : cs) c->k_prep = 0;
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
         LZX_HIP(hipMemcpyAsync(c->d_io, x, sizeof(double) * c->n, hipMemcpyHostToDevice, c->stream));
@@ -639,6 +659,7 @@ static int multout_run(std::vector<lzx_ctx *> &cs, const double *t, u32 k, doubl
     const bool multi = lzx_exchanges(c0);
     for (lzx_ctx *c : cs)
         if (c->k_last < k) LZX_FAIL(LZX_ERR_STATE, "lzx_multout_f64: the resident basis has %u vectors, %u asked", c->k_last, k);
+    for (lzx_ctx *c : cs) c->k_prep = 0;   // uses the work vectors (see spmv_run)
     std::vector<const double *> src(cs.size());
     std::vector<double *> dst(cs.size());
     for (lzx_ctx *c : cs) {
@@ -727,6 +748,7 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
 {
     if (!c || reps == 0 || !avg_ms) LZX_FAIL(LZX_ERR_ARG, "lzx_bench_spmv: bad argument");
     if (!c->d_row_ptr || !c->d_v) LZX_FAIL(LZX_ERR_STATE, "no graph has been handed over");
+    c->k_prep = 0;   // uses the work vectors (see spmv_run)
     LZX_HIP(hipSetDevice(c->device));
     // a non-trivial resident input: x = 1 everywhere
     std::vector<double> ones(c->n, 1.0);

@@ -62,6 +62,7 @@ int lzx_graph_release(lzx_ctx *c)
     lzx_pb_release(c);
     c->q_cols = 0;
     c->k_last = 0;
+    c->k_prep = 0;   // a prepared start vector lived in the buffers just freed
     c->n = c->nnz = 0;
     return LZX_OK;
 }
@@ -590,14 +591,16 @@ static int csr_from_keys_dev(lzx_ctx *c, u64 n, u64 *d_keys, u64 nkeys)
     return lzx_graph_prepare(c);
 }
 
-__global__ void k_edges_to_keys(const u32 *src, const u32 *dst, u64 m, u64 n, u64 *keys)
+__global__ void k_edges_to_keys(const u32 *src, const u32 *dst, u64 m, u64 n, u64 *keys, u32 *bad)
 {
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
     const u64 u = src[e], v = dst[e];
-    const bool ok = (u != v) && u < n && v < n;
+    // a self loop is ONE diagonal entry, as in the std::set build (both inserted keys are equal there)
+    const bool ok = u < n && v < n;
+    if (!ok) bad[0] = 1u;
     keys[2 * e] = ok ? ((u << 32) | v) : ~0ull;
-    keys[2 * e + 1] = ok ? ((v << 32) | u) : ~0ull;
+    keys[2 * e + 1] = ok && u != v ? ((v << 32) | u) : ~0ull;
 }
 
 __device__ __forceinline__ u64 gen_word(u64 seed, u64 ctr)
@@ -644,22 +647,26 @@ extern "C" int lzx_set_graph_edges(lzx_handle c, uint64_t n, uint64_t m, const u
 {
     if (!c || (m && (!src || !dst)) || n == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_edges: bad argument");
     LZX_HIP(hipSetDevice(c->device));
-    u32 *d_src = nullptr, *d_dst = nullptr;
+    u32 *d_src = nullptr, *d_dst = nullptr, *d_bad = nullptr, bad = 0;
     u64 *d_keys = nullptr;
     LZX_TRY(dev_alloc(&d_src, m));
     if (dev_alloc(&d_dst, m) != LZX_OK) { dev_free(d_src); return LZX_ERR_NOMEM; }
     if (dev_alloc(&d_keys, 2 * m) != LZX_OK) { dev_free(d_src); dev_free(d_dst); return LZX_ERR_NOMEM; }
+    if (dev_alloc(&d_bad, 1) != LZX_OK) { dev_free(d_src); dev_free(d_dst); dev_free(d_keys); return LZX_ERR_NOMEM; }
     hipError_t e = hipSuccess;
     if (m) {
         e = hipMemcpyAsync(d_src, src, sizeof(u32) * m, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst, sizeof(u32) * m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), c->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_edges_to_keys, dim3((u32)((m + 255) / 256)), dim3(256), 0, c->stream, d_src, d_dst, m, n, d_keys);
-            e = hipStreamSynchronize(c->stream);
+            hipLaunchKernelGGL(k_edges_to_keys, dim3((u32)((m + 255) / 256)), dim3(256), 0, c->stream, d_src, d_dst, m, n, d_keys, d_bad);
+            e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
     }
-    dev_free(d_src); dev_free(d_dst);
+    dev_free(d_src); dev_free(d_dst); dev_free(d_bad);
     if (e != hipSuccess) { dev_free(d_keys); LZX_FAIL(LZX_ERR_HIP, "edge upload: %s", hipGetErrorString(e)); }
+    if (bad) { dev_free(d_keys); LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_edges: an endpoint is >= n"); }
     return csr_from_keys_dev(c, n, d_keys, 2 * m);
 }
 
@@ -680,6 +687,15 @@ extern "C" int lzx_gen_graph(lzx_handle c, int kind, uint32_t scale, uint64_t n,
     return csr_from_keys_dev(c, n, d_keys, 2 * draws);
 }
 
+// flag[0] = 1 if any column index is out of range (the reshaping kernels index tables by it unchecked)
+__global__ void k_check_cols(const u32 *col_idx, u64 nnz, u32 n, u32 *flag)
+{
+    const u64 nthreads = (u64)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += nthreads) bad |= col_idx[i] >= n;
+    if (bad) flag[0] = 1u;
+}
+
 static int set_csr_common(lzx_ctx *c, u64 n, u64 nnz, const u64 *row_ptr64, const u32 *row_ptr32, const u32 *col_idx)
 {
     if (!c || n == 0 || (!row_ptr64 && !row_ptr32) || (nnz && !col_idx)) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: bad argument");
@@ -691,6 +707,9 @@ static int set_csr_common(lzx_ctx *c, u64 n, u64 nnz, const u64 *row_ptr64, cons
         row_ptr64 = widened.data();
     }
     if (row_ptr64[0] != 0 || row_ptr64[n] != nnz) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: row_ptr[0] must be 0 and row_ptr[n] must equal nnz");
+    if (n > 0xffffffffull) LZX_FAIL(LZX_ERR_LIMIT, "lzx_set_graph_csr: more than 2^32 vertices");
+    for (u64 i = 0; i < n; ++i)
+        if (row_ptr64[i] > row_ptr64[i + 1]) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: row_ptr decreases at row %llu", (unsigned long long)i);
     lzx_graph_release(c);
     c->n = n;
     c->nnz = nnz;
@@ -698,6 +717,19 @@ static int set_csr_common(lzx_ctx *c, u64 n, u64 nnz, const u64 *row_ptr64, cons
     LZX_TRY(dev_alloc(&c->d_col_idx, nnz));
     LZX_HIP(hipMemcpyAsync(c->d_row_ptr, row_ptr64, sizeof(u64) * (n + 1), hipMemcpyHostToDevice, c->stream));
     if (nnz) LZX_HIP(hipMemcpyAsync(c->d_col_idx, col_idx, sizeof(u32) * nnz, hipMemcpyHostToDevice, c->stream));
+    if (nnz) {   // a caller's out-of-range column would index the reshaping tables out of bounds: refuse it here
+        u32 *d_flag = nullptr, flag = 0;
+        LZX_TRY(dev_alloc(&d_flag, 1));
+        LZX_HIP(hipMemsetAsync(d_flag, 0, sizeof(u32), c->stream));
+        k_check_cols<<<1024, 256, 0, c->stream>>>(c->d_col_idx, nnz, (u32)n, d_flag);
+        LZX_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        LZX_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(d_flag);
+        if (flag) {
+            lzx_graph_release(c);
+            LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: a column index is >= n");
+        }
+    }
     LZX_HIP(hipStreamSynchronize(c->stream));
     return lzx_graph_prepare(c);
 }

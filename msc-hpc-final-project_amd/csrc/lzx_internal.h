@@ -165,6 +165,11 @@ struct lzx_ctx {
     u32 *d_pb_multi = nullptr;         // [pb_n_multi][4] row, first slot, items, slot stride: rows of bands cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows
     uint8_t *d_pb_long_multi = nullptr; // [n_long64] 1: the split row is also listed in d_pb_multi
+    u32 *d_pb_items2 = nullptr;        // [pb_n_items][8] the persistent gather pass's records, largest item first:
+                                       // begin, end, first row, rows, slots per row, total slot or ~0, 0, 0
+    u32 *d_pb_queue = nullptr;         // [4] ticket counters of the persistent passes: scatter chunk 0, chunk 1, gather
+    u32 pb_qbase[4] = {0, 0, 0, 0};    // value each counter will have when its next launch starts
+    int64_t pb_persist_opt = -1;       // persistent passes: -1/1 on, 0 = one workgroup per unit / static item lists
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;
     u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)

@@ -656,6 +656,348 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
     if (threadIdx.x == 0) partials[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
+
+// ---- persistent forms of the two passes (default) ---------------------------------------------------------------
+// Both passes above start every work unit cold: a unit record, then the tables it points to, then the first loads --
+// three dependent memory round trips (plus, in the scatter pass, the 128 KiB band) before a workgroup streams, with one
+// (scatter) or two (gather) workgroups per CU to hide them behind.  unit_bench (tools/unit_bench.hip) shows the inner
+// loops alone reach 6.1 TB/s (gather) and 5.1 TB/s (scatter, read + written) at this very occupancy, against 3.8 and
+// 4.3 TB/s of the passes.  Here a workgroup stays resident and draws units from a ticket counter (so the hardware's
+// dynamic balancing is kept): the next ticket and the next unit's record arrive while the current unit streams, and in
+// the scatter pass the next unit's x band is fetched into registers meanwhile (and not at all when the band stays).
+// Tickets: t = atomicAdd(counter, 1) - base; a workgroup stops at its first t >= n, so a launch of G workgroups
+// advances the counter by exactly n + G, which the host adds to `base` for the next launch: no reset between launches.
+
+template <u32 CB>
+__global__ void __launch_bounds__(1024)
+k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol,
+              const u32 *q_dst, const double *__restrict__ x, u64 xlen, double *val)
+{
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // CB staged values + a zero for padding
+    u32 *tick = reinterpret_cast<u32 *>(tile + CB + 2 + 16 * 66);   // [2]
+    const u32 lane = threadIdx.x & 63;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr u32 W = 1024 / 64;
+    constexpr u32 PRE = CB / 2048;                                  // 16-byte loads per thread for one band
+    const u64 xlen2 = xlen / 2;                                      // xlen is even: a double2 is inside or outside
+
+    if (threadIdx.x == 0) {
+        const u32 t0 = atomicAdd(queue, 1u) - qbase;
+        tick[0] = t0;
+        tick[1] = t0 < n_units ? atomicAdd(queue, 1u) - qbase : 0xffffffffu;
+    }
+    if (threadIdx.x < 2) tile[CB + threadIdx.x] = 0.0;
+    for (u32 j = threadIdx.x; j < 16 * 66; j += 1024) tile[CB + 2 + j] = 0.0;   // the wavefronts' carry slots
+    __syncthreads();
+    u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
+    u32 nxt = (u32)__builtin_amdgcn_readfirstlane((int)tick[1]);
+    if (cur >= n_units) return;
+    u32 band = (u32)__builtin_amdgcn_readfirstlane((int)unit[5 * cur]);
+    {   // the first band: staged directly (one round trip)
+        const double2 *src = reinterpret_cast<const double2 *>(x) + (u64)band * (CB / 2);
+        const u64 b2 = (u64)band * (CB / 2);
+        double2 t[PRE];
+#pragma unroll
+        for (u32 u = 0; u < PRE; ++u) {
+            const u32 j = threadIdx.x + u * 1024;
+            t[u] = b2 + j < xlen2 ? src[j] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (u32 u = 0; u < PRE; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = t[u];
+    }
+    __syncthreads();
+    double *carry = tile + CB + 2 + wv * 66;
+    for (;;) {
+        const u32 s_beg = (u32)__builtin_amdgcn_readfirstlane((int)unit[5 * cur + 1]);
+        const u32 s_end = (u32)__builtin_amdgcn_readfirstlane((int)unit[5 * cur + 2]);
+        const u32 q_beg = (u32)__builtin_amdgcn_readfirstlane((int)unit[5 * cur + 3]);
+        const u32 q_end = (u32)__builtin_amdgcn_readfirstlane((int)unit[5 * cur + 4]);
+        const bool have_next = nxt < n_units;
+        u32 t2 = 0xffffffffu;
+        if (threadIdx.x == 0 && have_next) t2 = atomicAdd(queue, 1u) - qbase;   // arrives while this unit streams
+        const u32 band_next = have_next ? (u32)__builtin_amdgcn_readfirstlane((int)unit[5 * nxt]) : band;
+        const bool restage = band_next != band;
+        double2 pre[PRE];
+        if (restage) {
+            const double2 *src = reinterpret_cast<const double2 *>(x) + (u64)band_next * (CB / 2);
+            const u64 b2 = (u64)band_next * (CB / 2);
+#pragma unroll
+            for (u32 u = 0; u < PRE; ++u) {
+                const u32 j = threadIdx.x + u * 1024;
+                pre[u] = b2 + j < xlen2 ? src[j] : make_double2(0.0, 0.0);
+            }
+        }
+        {   // ---- reduced steps (see k_pb_scatter)
+            auto body = [&](const uint4 &c, u32 pos) {
+                double xv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = tile[pbr_half(c, e) & 0x7fffu];
+                u32 ends = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ends |= pbr_flag(c, e) << e;
+                const bool has = ends != 0;
+                const int last = has ? 31 - __clz((int)ends) : -1;
+                double tail = 0.0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e > last) tail += xv[e];
+                const unsigned long long holders = __ballot(has);
+                const unsigned long long before = holders & ((1ull << lane) - 1ull);
+                const u32 from = before ? 64u - (u32)__clzll((long long)before) : 0u;
+                atomicAdd(&carry[has ? lane + 1 : from], tail);
+                __builtin_amdgcn_wave_barrier();
+                double s = has ? carry[from] : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                if (has) carry[from] = 0.0;
+                double *out = val + pos;
+                u32 done = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool f = (ends >> e) & 1u;
+                    s += xv[e];
+                    const unsigned long long m = __ballot(f);
+                    if (m) {
+                        if (f) {
+                            out[done + lanes_below(m)] = s;
+                            s = 0.0;
+                        }
+                        done += (u32)__popcll(m);
+                    }
+                }
+            };
+            u32 s = s_beg + wv;
+            for (; s + 3 * W < s_end; s += 4 * W) {
+                uint4 c[4];
+                u32 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                    b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) body(c[u], b[u]);
+            }
+            for (; s < s_end; s += W) body(scode[(size_t)s * 64 + lane], (u32)__builtin_amdgcn_readfirstlane((int)sbase[s]));
+        }
+        // ---- plain quads (see k_pb_scatter)
+        for (u32 blk = q_beg + wv * 256u; blk < q_end; blk += W * 256u) {
+            const u32 wend = blk + 256u < q_end ? blk + 256u : q_end;
+            u32 j = blk + lane;
+            for (; j + 3 * 64 < wend; j += 4 * 64) {
+                uint2 c[4];
+                u32 d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    c[u] = q_lcol[j + u * 64];
+                    d[u] = q_dst[j + u * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double2 lo, hi;
+                    lo.x = tile[c[u].x & 0xffffu];
+                    lo.y = tile[c[u].x >> 16];
+                    hi.x = tile[c[u].y & 0xffffu];
+                    hi.y = tile[c[u].y >> 16];
+                    double2 *out = reinterpret_cast<double2 *>(val + d[u]);
+                    out[0] = lo;
+                    out[1] = hi;
+                }
+            }
+            for (; j < wend; j += 64) {
+                const uint2 c = q_lcol[j];
+                double2 lo, hi;
+                lo.x = tile[c.x & 0xffffu];
+                lo.y = tile[c.x >> 16];
+                hi.x = tile[c.y & 0xffffu];
+                hi.y = tile[c.y >> 16];
+                double2 *out = reinterpret_cast<double2 *>(val + q_dst[j]);
+                out[0] = lo;
+                out[1] = hi;
+            }
+        }
+        if (threadIdx.x == 0) tick[0] = t2;
+        __syncthreads();                      // every wavefront is done with the band in LDS
+        if (!have_next) break;
+        if (restage) {
+#pragma unroll
+            for (u32 u = 0; u < PRE; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = pre[u];
+        }
+        const u32 t2_all = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
+        __syncthreads();
+        cur = nxt;
+        nxt = t2_all;
+        band = band_next;
+    }
+}
+
+// item record (two uint4): {begin, end, first row, rows} {slots per row, total slot or ~0, -, -}
+__global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
+k_pb_gather2(const uint4 *items2, u32 n_items, u32 *queue, u32 qbase, const uint16_t *lslot, const double *val, double *v,
+             const double *__restrict__ q_loc, double *part, double *partials)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
+    constexpr u32 TILE = LZX_PB_RB + 8;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    double *ytile = lds + (size_t)wv * TILE;
+    double *wsum = lds + (size_t)WAVES * TILE;
+    u32 *tick = reinterpret_cast<u32 *>(wsum + WAVES);
+    double dot = 0.0;
+    if (tid == 0) tick[0] = atomicAdd(queue, 1u) - qbase;
+    __syncthreads();
+    u32 it = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+    if (it < n_items) {
+        r0 = items2[2 * (size_t)it];
+        r1 = items2[2 * (size_t)it + 1];
+    }
+    __syncthreads();                          // tick[0] is free again
+    while (it < n_items) {
+        const u32 beg = (u32)__builtin_amdgcn_readfirstlane((int)r0.x), end = (u32)__builtin_amdgcn_readfirstlane((int)r0.y);
+        const u32 row0 = (u32)__builtin_amdgcn_readfirstlane((int)r0.z), rows = (u32)__builtin_amdgcn_readfirstlane((int)r0.w);
+        const u32 rep = (u32)__builtin_amdgcn_readfirstlane((int)r1.x), slot = (u32)__builtin_amdgcn_readfirstlane((int)r1.y);
+        u32 tn = 0xffffffffu;
+        if (tid == 0) tn = atomicAdd(queue, 1u) - qbase;     // the next ticket travels while this item streams
+        double acc = 0.0;                                      // rows == 1
+        double vv[2] = {0.0, 0.0}, qq[2] = {0.0, 0.0};        // this thread's rows of the fold, fetched ahead
+        if (rows == 1) {
+            u32 i = beg + tid;
+            for (; i + 7 * LZX_PB_GATHER_BLOCK < end; i += 8 * LZX_PB_GATHER_BLOCK) {
+                double a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = val[i + u * LZX_PB_GATHER_BLOCK];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += a[u];
+            }
+            for (; i < end; i += LZX_PB_GATHER_BLOCK) acc += val[i];
+            acc = wave_sum_pb(acc);
+            if (lane == 0) wsum[wv] = acc;
+        } else {
+            if (slot == 0xffffffffu) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
+                    if (j < rows) {
+                        vv[u] = v[row0 + j];
+                        qq[u] = q_loc[row0 + j];
+                    }
+                }
+            }
+            const u32 slots = rows * rep;
+            for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
+            __builtin_amdgcn_wave_barrier();
+            const u32 blocks = (end - beg) / 128u;
+            // the band's tail (< 128 values), wavefront 0: fetched first, added last
+            double tv[2] = {0.0, 0.0};
+            u32 ts[2] = {LZX_PB_RB, LZX_PB_RB};
+            if (wv == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const u32 i = beg + blocks * 128u + lane + u * 64;
+                    if (i < end) {
+                        tv[u] = val[i];
+                        ts[u] = lslot[i];
+                    }
+                }
+            }
+            u32 kb = wv;
+            for (; kb + 7 * WAVES < blocks; kb += 8 * WAVES) {
+                double2 av[8];
+                u32 sv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const u32 p = beg + (kb + u * WAVES) * 128u + lane * 2;
+                    av[u] = *reinterpret_cast<const double2 *>(val + p);
+                    sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                    atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                }
+            }
+            {   // up to 7 more blocks of this wavefront: all fetched before the first add
+                double2 av[7];
+                u32 sv[7];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    const u32 k = kb + u * WAVES;
+                    if (k < blocks) {
+                        const u32 p = beg + k * 128u + lane * 2;
+                        av[u] = *reinterpret_cast<const double2 *>(val + p);
+                        sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    const u32 k = kb + u * WAVES;
+                    if (k < blocks) {
+                        atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                        atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                    }
+                }
+            }
+            if (wv == 0) {
+                atomicAdd(&ytile[ts[0]], tv[0]);
+                atomicAdd(&ytile[ts[1]], tv[1]);
+            }
+        }
+        if (tid == 0) tick[0] = tn;
+        __syncthreads();
+        const u32 nx = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+        if (nx < n_items) {                    // in flight during the fold
+            n0 = items2[2 * (size_t)nx];
+            n1 = items2[2 * (size_t)nx + 1];
+        }
+        if (rows == 1) {
+            if (tid == 0) {
+                double t = 0.0;
+                for (u32 w = 0; w < WAVES; ++w) t += wsum[w];
+                if (slot == 0xffffffffu) {
+                    v[row0] += t;
+                    dot += t * q_loc[row0];
+                } else {
+                    part[slot] = t;
+                }
+            }
+        } else if (slot == 0xffffffffu) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
+                if (j < rows) {
+                    double y = 0.0;
+                    for (u32 w = 0; w < WAVES; ++w)
+                        for (u32 t = 0; t < rep; ++t) y += lds[(size_t)w * TILE + j * rep + t];
+                    v[row0 + j] = vv[u] + y;
+                    dot += y * qq[u];
+                }
+            }
+        } else {
+            for (u32 j = tid; j < rows; j += LZX_PB_GATHER_BLOCK) {
+                double y = 0.0;
+                for (u32 w = 0; w < WAVES; ++w)
+                    for (u32 t = 0; t < rep; ++t) y += lds[(size_t)w * TILE + j * rep + t];
+                part[slot + j] = y;
+            }
+        }
+        __syncthreads();                      // tiles, wsum and tick are free
+        it = nx;
+        r0 = n0;
+        r1 = n1;
+    }
+    dot = wave_sum_pb(dot);
+    __syncthreads();
+    if (lane == 0) wsum[wv] = dot;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (u32 i = 0; i < WAVES; ++i) s += wsum[i];
+        partials[blockIdx.x] = s;
+    }
+}
+
 template <typename T>
 int pb_alloc(T **p, u64 count)
 {
@@ -681,6 +1023,8 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_row0);
     pb_free(c->d_pb_rep);
     pb_free(c->d_pb_items);
+    pb_free(c->d_pb_items2);
+    pb_free(c->d_pb_queue);
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
     pb_free(c->d_pb_long_multi);
@@ -1047,8 +1391,9 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(ar.get(&d_rstart_pad, (u64)nr + 1));
     LZX_HIP(hipMemcpyAsync(d_rstart_pad, rstart.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
     LZX_TRY(pb_alloc(&c->d_pb_lrow, len + 8)); LZX_TRY(pb_alloc(&c->d_pb_rep, (u64)nr));
+    std::vector<u32> rep((size_t)nr, 1u);
     {
-        std::vector<u32> step0((size_t)nr + 1), rep((size_t)nr, 1u);
+        std::vector<u32> step0((size_t)nr + 1);
         u64 steps = 0;
         for (u32 R = 0; R < nr; ++R) {
             step0[R] = (u32)steps;
@@ -1102,6 +1447,27 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     }
     c->pb_n_items = (u32)(items.size() / 4);
     c->pb_n_multi = (u32)(multi.size() / 4);
+    {   // records of the persistent gather pass: everything an item needs in one place, largest item first (tickets are
+        // drawn in this order, so the long items start early and the short ones even out the end)
+        std::vector<u32> order(c->pb_n_items);
+        for (u32 i = 0; i < c->pb_n_items; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+            return items[4 * (size_t)a + 2] - items[4 * (size_t)a + 1] > items[4 * (size_t)b + 2] - items[4 * (size_t)b + 1];
+        });
+        std::vector<u32> rec((size_t)c->pb_n_items * 8, 0u);
+        for (u32 i = 0; i < c->pb_n_items; ++i) {
+            const u32 *it = &items[4 * (size_t)order[i]];
+            const u32 R = it[0];
+            u32 *o = &rec[8 * (size_t)i];
+            o[0] = it[1]; o[1] = it[2]; o[2] = row0[R]; o[3] = row0[R + 1] - row0[R]; o[4] = rep[R]; o[5] = it[3];
+        }
+        LZX_TRY(pb_alloc(&c->d_pb_items2, rec.size()));
+        if (!rec.empty()) LZX_HIP(hipMemcpyAsync(c->d_pb_items2, rec.data(), sizeof(u32) * rec.size(), hipMemcpyHostToDevice, st));
+        LZX_TRY(pb_alloc(&c->d_pb_queue, 4));
+        LZX_HIP(hipMemsetAsync(c->d_pb_queue, 0, sizeof(u32) * 4, st));
+        for (u32 &b : c->pb_qbase) b = 0;
+        LZX_HIP(hipStreamSynchronize(st));
+    }
     {   // split rows (the first n_long64 local rows) that are also rows of a multi-item band
         std::vector<uint8_t> flag((size_t)c->n_long64 + 1, 0);
         for (size_t i = 0; i < multi.size(); i += 4)
@@ -1161,10 +1527,24 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                                  : (ablate ? k_pb_scatter<LZX_PB_CB, true> : k_pb_scatter<LZX_PB_CB, false>);
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    const bool persistent = c->pb_persist_opt != 0 && !ablate;
+    const size_t lds1p = lds1 + 16;
+    auto kern2 = c->pb_cb == 8192 ? k_pb_scatter2<8192> : k_pb_scatter2<LZX_PB_CB>;
+    if (c->pb_units && persistent)
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1p));
     auto scatter = [&](u32 u0, u32 u1) {
-        if (u1 > u0)
-            hipLaunchKernelGGL(kern, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
-                               c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val, ablate);
+        if (u1 <= u0) return;
+        if (persistent) {
+            const u32 q = u0 == 0 ? 0u : 1u, n = u1 - u0;
+            const u32 grid = std::min<u32>(n, (u32)c->cu_count * (c->pb_cb == 8192 ? 2u : 1u));
+            hipLaunchKernelGGL(kern2, dim3(grid), dim3(1024), lds1p, c->stream, c->d_pb_unit + 5 * (size_t)u0, n, c->d_pb_queue + q,
+                               c->pb_qbase[q], c->d_pbr_code, c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol),
+                               c->d_pb_dst, x, c->xlen, c->d_pb_val);
+            c->pb_qbase[q] += n + grid;
+            return;
+        }
+        hipLaunchKernelGGL(kern, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
+                           c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val, ablate);
     };
     // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
     if (c->phase_mask_opt & 4) {
@@ -1181,7 +1561,17 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);
     LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    if (!(c->phase_mask_opt & 8))
+    if (c->phase_mask_opt & 8) {
+        // experiment: scatter pass alone
+    } else if (persistent) {
+        const size_t lds2p = lds2 + 16;
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather2),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p));
+        hipLaunchKernelGGL(k_pb_gather2, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2p, c->stream,
+                           reinterpret_cast<const uint4 *>(c->d_pb_items2), c->pb_n_items, c->d_pb_queue + 2, c->pb_qbase[2],
+                           c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials);
+        c->pb_qbase[2] += c->pb_n_items + c->pb_gather_grid;
+    } else
     hipLaunchKernelGGL(k_pb_gather, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_lrow,
                        c->d_pb_val, v, q_loc, c->d_pb_part, partials);

@@ -1,11 +1,20 @@
 // adjMatrix.cc -- loader and seeded generators for the adjMatrix drop-in (see adjMatrix.h).
 #include "adjMatrix.h"
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cassert>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <iterator>
 #include <stdexcept>
+#include <thread>
+
+#include "lzx.h"
 
 namespace {
 // SplitMix64 as a counter-based generator: word c of stream `seed`.  Same integer specification as the
@@ -18,12 +27,23 @@ inline std::uint64_t word(std::uint64_t seed, std::uint64_t c) {
 }
 inline std::uint64_t below(std::uint64_t w, std::uint64_t n) { return ((w >> 32) * n) >> 32; }
 inline std::uint64_t key(std::uint64_t r, std::uint64_t c) { return (r << 32) | c; }
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+bool env_on(const char *name) {
+  const char *v = std::getenv(name);
+  return v && *v && *v != '0';
+}
+void lzx_or_throw(int rc, const char *what) {
+  if (rc != LZX_OK) throw std::runtime_error(std::string(what) + ": " + lzx_last_error());
+}
 }  // namespace
 
 void adjMatrix::release() {
   delete[] row_offset;
   delete[] col_idx;
   row_offset = col_idx = nullptr;
+  dev.reset();
 }
 
 void adjMatrix::steal(adjMatrix &rhs) {
@@ -34,8 +54,60 @@ void adjMatrix::steal(adjMatrix &rhs) {
   barabasi_degree = rhs.barabasi_degree;
   matrix_type = rhs.matrix_type;
   seed = rhs.seed;
+  dev = std::move(rhs.dev);
+  report = rhs.report;
   rhs.row_offset = rhs.col_idx = nullptr;
   rhs.n = rhs.edge_count = 0;
+}
+
+// One handle per configured GPU, wired as an in-process communicator when there are several
+// (parallel-two-cards drives its two cards from one process the same way).
+static std::shared_ptr<deviceGraph> make_handles() {
+  const std::vector<int> ids = lzx_host_devices();
+  if (ids.empty()) throw std::runtime_error("adjMatrix: no usable GPU (lzx_device_count() == 0)");
+  auto g = std::make_shared<deviceGraph>();
+  for (int id : ids) {
+    lzx_handle h = nullptr;
+    lzx_or_throw(lzx_create(&h, id), "lzx_create");
+    g->ranks.push_back(h);
+  }
+  if (g->ranks.size() > 1) lzx_or_throw(lzx_comm_init_local(g->ranks.data(), static_cast<int>(g->ranks.size())), "lzx_comm_init_local");
+  return g;
+}
+
+std::shared_ptr<deviceGraph> adjMatrix::device_graph() const {
+  if (dev) return dev;
+  if (!row_offset) throw std::runtime_error("adjMatrix: empty graph");
+  const auto t0 = std::chrono::steady_clock::now();
+  auto g = make_handles();
+  // stored entries: row_offset[n] (2 * edge_count is one too many per self loop of the file)
+  for (lzx_ctx *h : g->ranks) lzx_or_throw(lzx_set_graph_csr32(h, n, row_offset[n], row_offset, col_idx), "lzx_set_graph_csr32");
+  g->setup_ms = seconds_since(t0) * 1e3;
+  dev = g;
+  return dev;
+}
+
+// Device ingest: the endpoint pairs go to the GPU(s) as they were parsed; symmetrising, sorting and de-duplicating
+// happen there (lzx_set_graph_edges) and the CSR comes back for the CPU path.  false = no GPU (caller sorts on the host).
+bool adjMatrix::ingest_on_device(const std::vector<unsigned> &src, const std::vector<unsigned> &dst) {
+  if (env_on("LZX_HOST_INGEST") || lzx_host_devices().empty()) return false;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto g = make_handles();
+  for (lzx_ctx *h : g->ranks) lzx_or_throw(lzx_set_graph_edges(h, n, src.size(), src.data(), dst.data()), "lzx_set_graph_edges");
+  lzx_graph_info gi;
+  lzx_or_throw(lzx_get_graph_info(g->ranks[0], &gi), "lzx_get_graph_info");
+  if (gi.nnz > 0xffffffffull) throw std::runtime_error("adjMatrix: more than 2^32 stored entries (unsigned col_idx offsets)");
+  std::vector<std::uint64_t> rp(static_cast<std::size_t>(n) + 1);
+  release();
+  row_offset = new unsigned[static_cast<std::size_t>(n) + 1];
+  col_idx = new unsigned[std::max<std::size_t>(gi.nnz, 1)];
+  lzx_or_throw(lzx_get_graph_csr(g->ranks[0], rp.data(), col_idx), "lzx_get_graph_csr");
+  for (std::size_t i = 0; i <= n; ++i) row_offset[i] = static_cast<unsigned>(rp[i]);
+  edge_count = static_cast<unsigned>(gi.nnz / 2);
+  g->ingested = true;
+  g->setup_ms = seconds_since(t0) * 1e3;
+  dev = g;
+  return true;
 }
 
 void adjMatrix::csr_from_keys(std::vector<std::uint64_t> &keys) {
@@ -72,28 +144,158 @@ adjMatrix::adjMatrix(unsigned N, unsigned E) : n{N}, matrix_type{'r'} {
 }
 
 void adjMatrix::populate_sparse_matrix(std::ifstream &f) {
-  // Slurp the rest of the stream and parse unsigned integers by hand: an order of magnitude faster
-  // than operator>> and independent of line structure, like the reference's `f >> col >> row`.
+  // Slurp the rest of the stream: parsing by hand is an order of magnitude faster than operator>> and, like the
+  // reference's `f >> col >> row`, independent of line structure.
   std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-  std::vector<std::uint64_t> keys;
-  keys.reserve(2 * static_cast<std::size_t>(edge_count));
-  const char *p = text.data(), *end = p + text.size();
-  auto next = [&](std::uint64_t &out) -> bool {
-    while (p < end && (*p < '0' || *p > '9')) ++p;
-    if (p >= end) return false;
-    std::uint64_t v = 0;
-    while (p < end && *p >= '0' && *p <= '9') v = v * 10 + static_cast<std::uint64_t>(*p++ - '0');
-    out = v;
-    return true;
-  };
-  for (unsigned e = 0; e < edge_count; ++e) {
-    std::uint64_t col, row;
-    if (!next(col) || !next(row)) break;  // short file: keep what was read (the reference reads garbage)
-    if (col == 0 || row == 0 || col > n || row > n) throw std::runtime_error("adjMatrix: vertex id out of range");
-    keys.push_back(key(row - 1, col - 1));  // files are 1-indexed
-    keys.push_back(key(col - 1, row - 1));
+  build_from_text(text);
+}
+
+// Parse up to edge_count "col row" pairs (1-indexed) and build the CSR.  The text is cut at line ends into one
+// piece per thread; pieces are parsed independently and joined in order, so the first edge_count pairs are the
+// same ones a sequential reader takes.
+void adjMatrix::build_from_text(const std::string &text) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const char *base = text.data();
+  const std::size_t len = text.size();
+  unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (len < (1u << 20)) threads = 1;
+  if (const char *e = std::getenv("LZX_PARSE_THREADS")) threads = std::max(1, std::atoi(e));
+  std::vector<std::size_t> cut(threads + 1, len);
+  cut[0] = 0;
+  for (unsigned t = 1; t < threads; ++t) {
+    std::size_t p = std::max(cut[t - 1], len / threads * t);
+    while (p < len && base[p] != '\n') ++p;   // a piece ends behind a line end
+    cut[t] = p;
   }
-  csr_from_keys(keys);
+  std::vector<std::vector<unsigned>> ps(threads), pd(threads);
+  std::vector<int> bad(threads, 0);
+  auto parse = [&](unsigned t) {
+    const char *p = base + cut[t], *end = base + cut[t + 1];
+    std::vector<unsigned> &s = ps[t], &d = pd[t];
+    s.reserve((cut[t + 1] - cut[t]) / 12 + 16);
+    d.reserve((cut[t + 1] - cut[t]) / 12 + 16);
+    auto next = [&](std::uint64_t &out) -> bool {
+      while (p < end && (*p < '0' || *p > '9')) ++p;
+      if (p >= end) return false;
+      std::uint64_t v = 0;
+      while (p < end && *p >= '0' && *p <= '9') v = v * 10 + static_cast<std::uint64_t>(*p++ - '0');
+      out = v;
+      return true;
+    };
+    std::uint64_t col, row;
+    while (next(col) && next(row)) {
+      if (col == 0 || row == 0 || col > n || row > n) { bad[t] = 1; return; }
+      s.push_back(static_cast<unsigned>(row - 1));   // files are 1-indexed
+      d.push_back(static_cast<unsigned>(col - 1));
+    }
+  };
+  if (threads == 1) parse(0);
+  else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(parse, t);
+    for (auto &th : pool) th.join();
+  }
+  // join in order, up to the declared edge count (a short file keeps what was read; the reference reads garbage)
+  std::vector<unsigned> src, dst;
+  src.reserve(edge_count);
+  dst.reserve(edge_count);
+  for (unsigned t = 0; t < threads && src.size() < edge_count; ++t) {
+    const std::size_t take = std::min<std::size_t>(ps[t].size(), edge_count - src.size());
+    // an out-of-range id only counts when it lies among the pairs that are actually taken
+    if (bad[t] && take == ps[t].size()) throw std::runtime_error("adjMatrix: vertex id out of range");
+    src.insert(src.end(), ps[t].begin(), ps[t].begin() + take);
+    dst.insert(dst.end(), pd[t].begin(), pd[t].begin() + take);
+    std::vector<unsigned>().swap(ps[t]);
+    std::vector<unsigned>().swap(pd[t]);
+  }
+  report = loadReport{};
+  report.threads = threads;
+  report.parse_s = seconds_since(t0);
+  const auto t1 = std::chrono::steady_clock::now();
+  if (ingest_on_device(src, dst)) {
+    report.on_device = true;
+  } else {
+    std::vector<std::uint64_t> keys;
+    keys.reserve(2 * src.size());
+    for (std::size_t e = 0; e < src.size(); ++e) {
+      keys.push_back(key(src[e], dst[e]));
+      keys.push_back(key(dst[e], src[e]));
+    }
+    csr_from_keys(keys);
+  }
+  report.build_s = seconds_since(t1);
+}
+
+namespace {
+struct cacheHeader {
+  char magic[8];
+  std::uint64_t src_size;
+  std::int64_t src_mtime_s, src_mtime_ns;
+  std::uint32_t n, edge_count;
+  std::uint64_t nnz;
+};
+const char kMagic[8] = {'L', 'Z', 'X', 'C', 'S', 'R', '1', 0};
+}  // namespace
+
+adjMatrix adjMatrix::load(const std::string &path) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) throw std::runtime_error("adjMatrix: cannot open " + path);
+  const std::string side = path + ".lzxcsr";
+  const bool use_cache = !env_on("LZX_NO_CSR_CACHE");
+  adjMatrix g;
+  g.matrix_type = 'f';
+  if (use_cache) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (FILE *f = std::fopen(side.c_str(), "rb")) {
+      cacheHeader h;
+      bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, kMagic, 8) == 0 &&
+                h.src_size == static_cast<std::uint64_t>(st.st_size) && h.src_mtime_s == static_cast<std::int64_t>(st.st_mtim.tv_sec) &&
+                h.src_mtime_ns == static_cast<std::int64_t>(st.st_mtim.tv_nsec) && h.nnz <= 0xffffffffull;
+      if (ok) {
+        g.n = h.n;
+        g.edge_count = h.edge_count;
+        g.row_offset = new unsigned[static_cast<std::size_t>(h.n) + 1];
+        g.col_idx = new unsigned[std::max<std::size_t>(h.nnz, 1)];
+        ok = std::fread(g.row_offset, sizeof(unsigned), static_cast<std::size_t>(h.n) + 1, f) == static_cast<std::size_t>(h.n) + 1 &&
+             std::fread(g.col_idx, sizeof(unsigned), h.nnz, f) == h.nnz && g.row_offset[h.n] == h.nnz;
+      }
+      std::fclose(f);
+      if (ok) {
+        g.report.from_cache = true;
+        g.report.cache_s = seconds_since(t0);
+        return g;
+      }
+      g.release();
+      g.n = g.edge_count = 0;
+    }
+  }
+  std::ifstream fs(path, std::ios::binary);
+  if (fs.fail()) throw std::runtime_error("adjMatrix: cannot open " + path);
+  unsigned n1 = 0, n2 = 0, e = 0;
+  fs >> n1 >> n2 >> e;
+  g.n = n2;          // `fs >> n >> n >> edges` (parallel-final/main.cu:62)
+  g.edge_count = e;
+  g.populate_sparse_matrix(fs);
+  if (use_cache) {   // best effort: a read-only directory just means no cache
+    const std::string tmp = side + ".tmp";
+    if (FILE *f = std::fopen(tmp.c_str(), "wb")) {
+      cacheHeader h;
+      std::memcpy(h.magic, kMagic, 8);
+      h.src_size = static_cast<std::uint64_t>(st.st_size);
+      h.src_mtime_s = static_cast<std::int64_t>(st.st_mtim.tv_sec);
+      h.src_mtime_ns = static_cast<std::int64_t>(st.st_mtim.tv_nsec);
+      h.n = g.n;
+      h.edge_count = g.edge_count;
+      h.nnz = g.row_offset[g.n];
+      const bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 &&
+                      std::fwrite(g.row_offset, sizeof(unsigned), static_cast<std::size_t>(g.n) + 1, f) == static_cast<std::size_t>(g.n) + 1 &&
+                      std::fwrite(g.col_idx, sizeof(unsigned), h.nnz, f) == h.nnz;
+      const bool closed = std::fclose(f) == 0;
+      if (ok && closed) std::rename(tmp.c_str(), side.c_str());
+      else std::remove(tmp.c_str());
+    }
+  }
+  return g;
 }
 
 void adjMatrix::generate_sparse_matrix(char c) {
@@ -205,7 +407,7 @@ void adjMatrix::print_full() const {
 
 std::ostream &operator<<(std::ostream &os, const adjMatrix &A) {
   os << "JA\n";
-  for (unsigned i = 0; i < 2 * A.edge_count; ++i) os << A.col_idx[i] << ' ';
+  for (unsigned i = 0; i < A.get_nnz(); ++i) os << A.col_idx[i] << ' ';
   os << "\nIA\n";
   for (unsigned i = 0; i <= A.n; ++i) os << A.row_offset[i] << ' ';
   return os;

@@ -9,14 +9,21 @@
 //   * row_offset[0] and the offsets of trailing empty rows are always written (the reference leaves
 //     them to whatever the heap held);
 //   * the random generators are seeded and reproducible (the reference seeds std::random_device,
-//     parallel-final/lib/make_graph.cc:23-24,61-62).
+//     parallel-final/lib/make_graph.cc:23-24,61-62);
+//   * ingest: the text is parsed by several threads and, when a GPU is present, symmetrised,
+//     sorted and de-duplicated there (lzx_set_graph_edges) -- the graph then already sits reshaped in HBM when a
+//     device decomposition asks for it; adjMatrix::load(path) adds a binary side-car cache of the CSR keyed by the
+//     text file's size and modification time.
 #pragma once
 
 #include <cstdint>
 #include <fstream>
 #include <iosfwd>
+#include <memory>
 #include <string>
 #include <vector>
+
+#include "device_graph.h"
 
 template <typename T> class eigenDecomp;
 template <typename T> class lanczosDecomp;
@@ -31,6 +38,9 @@ class adjMatrix {
   adjMatrix(unsigned N, unsigned m, char c);
   // G(N, E) uniform random graph.
   adjMatrix(unsigned N, unsigned E);
+  // The file constructor with the path known: "n n E" header read here, binary CSR side-car `<path>.lzxcsr` used when
+  // it matches the text file (size + mtime) and written after a parse (best effort; LZX_NO_CSR_CACHE=1 disables both).
+  static adjMatrix load(const std::string &path);
   // R-MAT graph (not in the reference; the benchmark family of BASELINE.json).
   static adjMatrix rmat(unsigned scale, unsigned N, std::uint64_t draws, std::uint64_t seed,
                         double a = 0.57, double b = 0.19, double c = 0.19);
@@ -46,6 +56,13 @@ class adjMatrix {
 
   unsigned get_n() const { return n; }
   unsigned get_edges() const { return edge_count; }
+  unsigned get_nnz() const { return row_offset ? row_offset[n] : 0; }   // stored entries (2 E, less one per self loop)
+  // How the last load went (seconds): text parse, CSR build (device ingest or host sort), cache read; and which path.
+  struct loadReport { double parse_s = 0, build_s = 0, cache_s = 0; bool from_cache = false, on_device = false; unsigned threads = 1; };
+  const loadReport &load_report() const { return report; }
+  // The graph on the GPU(s) (lzx_host_devices()): uploaded and reshaped on first use, kept for later decompositions.
+  // Throws std::runtime_error when there is no usable GPU or the hand-over fails.
+  std::shared_ptr<deviceGraph> device_graph() const;
   void set_seed(std::uint64_t s) { seed = s; }
 
   // Writes "<dir>/<type>n<N>e<E>": header "n n E", then "col row" (1-indexed, col > row) per edge.
@@ -65,8 +82,12 @@ class adjMatrix {
   unsigned barabasi_degree = 0;
   char matrix_type = 'f';
   std::uint64_t seed = 1234;
+  mutable std::shared_ptr<deviceGraph> dev;   // device-resident form, once somebody asked for it (or the ingest built it)
+  loadReport report;
 
   void populate_sparse_matrix(std::ifstream &f);
+  void build_from_text(const std::string &text);
+  bool ingest_on_device(const std::vector<unsigned> &src, const std::vector<unsigned> &dst);
   void generate_sparse_matrix(char c);
   void random_adj();
   void barabasi(unsigned m);

@@ -7,6 +7,10 @@
 //   cuda == false : Q is row-major n x k            (Q[j + row * k], parallel-final/lib/lanczos.cu:54)
 //   cuda == true  : Q is k contiguous vectors of n  (&Q[k * n],      parallel-final/lib/cu_lanczos.cu:126)
 // and multOut's `Qtrans` flag says which one it is given.
+// The device path borrows the adjMatrix's device-resident graph (adjMatrix::device_graph(): one handle per GPU of
+// lzx_host_devices(); several GPUs are driven from this one object, as parallel-two-cards/lib/cu_lanczos.cu:39-191
+// drives its two cards) and leaves the basis in HBM: the k * n host copy `Q` is only made when somebody reads it
+// (host multOut with Qtrans = true) -- cu_multOut / multOutAdaptive use the resident one.
 // Not reproduced: the destructor / free_mem defects (cudaFree of a host pointer, leak of Q_d:
 // cu_lanczos.h:75,84) and the silent half-built object after a failed allocation
 // (cu_lanczos.cu:38-72) -- a failed device path throws std::runtime_error with the lzx error text.
@@ -14,9 +18,11 @@
 
 #include <cmath>
 #include <cstdint>
+#include <memory>
 #include <string>
 
 #include "adjMatrix.h"
+#include "device_graph.h"
 
 struct lzx_ctx;
 
@@ -41,8 +47,11 @@ template <typename U, typename V> void check_ans(lanczosDecomp<U> &, lanczosDeco
 
 // Timings of the device path of the last constructed decomposition (milliseconds).
 struct lanczosTimings {
-  double loop_ms = 0, spmv_ms = 0, vec_ms = 0, setup_ms = 0;
+  double loop_ms = 0, spmv_ms = 0, vec_ms = 0, comm_ms = 0;
+  double setup_ms = 0;   // upload + reshaping of the graph, 0 when the adjMatrix already had it on the device
+  double fetch_ms = 0;   // download of the basis to the host, once somebody asked for it
   std::uint64_t spmv_bytes = 0;
+  unsigned gpus = 0;
 };
 
 template <typename T>
@@ -67,7 +76,10 @@ class lanczosDecomp {
   const T *answer() const { return ans; }
   const T *get_alpha() const { return alpha; }
   const T *get_beta() const { return beta; }
-  bool on_device() const { return engine != nullptr; }
+  bool on_device() const { return graph != nullptr; }
+  unsigned gpus() const { return graph ? static_cast<unsigned>(graph->ranks.size()) : 0; }
+  // The host copy of the basis (layout above); a device decomposition downloads it on the first call.
+  const T *basis() { ensure_host_basis(); return Q; }
 
   friend class eigenDecomp<T>;
   template <typename U> friend void multOut(lanczosDecomp<U> &, eigenDecomp<U> &, adjMatrix &, bool);
@@ -85,8 +97,12 @@ class lanczosDecomp {
   T *x = nullptr;      // starting vector          [n]
   T *ans = nullptr;    // e^A x once multOut ran   [n]
   T x_norm;
-  lzx_ctx *engine = nullptr;  // lzx handle of the device path (owns the resident basis)
+  std::shared_ptr<deviceGraph> graph;  // device path: the adjMatrix's graph on the GPU(s); the basis is resident there
   lanczosTimings times;
+
+  void ensure_host_basis();             // device path: Q <- resident basis (once)
+  void device_multout(const double *t, unsigned k, double *out);   // out = resident basis * t
+  static void evict_cb(void *self);     // another decomposition is about to overwrite the resident basis
 
   void decompose();     // CPU:    serial/lib/lanczos.cc:9-56 == parallel-final/lib/lanczos.cu:17-60
   void cu_decompose();  // MI355X: replaces parallel-final/lib/cu_lanczos.cu:20-142

@@ -59,7 +59,7 @@ static long dump_csr(const adjMatrix &A, unsigned *row_offset, unsigned *col_idx
   std::istringstream is(os.str());
   std::string tag;
   is >> tag;
-  const unsigned nnz = 2 * A.get_edges();
+  const unsigned nnz = A.get_nnz();
   if (nnz > max_nnz) { g_host_err = "col_idx buffer too small"; return -2; }
   for (unsigned i = 0; i < nnz; ++i) is >> col_idx[i];
   is >> tag;
@@ -122,6 +122,50 @@ long host_load_csr(const char *path, unsigned *row_offset, unsigned *col_idx, un
     fs >> n >> n >> edges;
     adjMatrix A(n, edges, fs);
     return dump_csr(A, row_offset, col_idx, max_nnz);
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
+// adjMatrix::load(path): parallel parser + device ingest (when a GPU is there) + binary side-car cache.
+// info[0] = read from the cache, info[1] = CSR built on the GPU, info[2] = parser threads, info[3] = stored entries.
+long host_load_path(const char *path, unsigned *row_offset, unsigned *col_idx, unsigned max_nnz, unsigned *info) {
+  try {
+    adjMatrix A = adjMatrix::load(path);
+    const adjMatrix::loadReport &r = A.load_report();
+    if (info) { info[0] = r.from_cache; info[1] = r.on_device; info[2] = r.threads; info[3] = A.get_nnz(); }
+    return dump_csr(A, row_offset, col_idx, max_nnz);
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
+// The whole pipeline on a path through adjMatrix::load, device decomposition spread over the GPUs of
+// lzx_host_set_devices(devices[0..ndev)) (handles may share a GPU).  device_multout: 0 host multOut (downloads the
+// basis lazily), 1 cu_multOut.  Returns n or < 0; gpus_used receives the number of handles the decomposition drove.
+long host_expm_path_devices(const char *path, unsigned k, const int *devices, int ndev, int device_multout, double *ans,
+                            unsigned ans_len, double *alpha, double *beta, unsigned *gpus_used) {
+  try {
+    lzx_host_set_devices(std::vector<int>(devices, devices + ndev));
+    struct reset { ~reset() { lzx_host_set_devices({}); } } guard;
+    adjMatrix A = adjMatrix::load(path);
+    const unsigned n = A.get_n();
+    if (ans_len < n) { g_host_err = "answer buffer too small"; return -2; }
+    std::vector<double> x(n, 1.0);
+    lanczosDecomp<double> L(A, k, x.data(), true);
+    if (gpus_used) *gpus_used = L.gpus();
+    if (alpha) std::copy(L.get_alpha(), L.get_alpha() + k, alpha);
+    if (beta && k > 1) std::copy(L.get_beta(), L.get_beta() + (k - 1), beta);
+    eigenDecomp<double> E(L);
+    if (device_multout) cu_multOut(L, E, A, true);
+    else multOut(L, E, A, true);
+    std::copy(L.answer(), L.answer() + n, ans);
+    // a second decomposition on the same graph re-uses the resident graph and evicts the first one's basis
+    lanczosDecomp<double> L2(A, k, x.data(), true);
+    if (L2.timings().setup_ms != 0.0) { g_host_err = "second decomposition uploaded the graph again"; return -4; }
+    return static_cast<long>(n);
   } catch (const std::exception &e) {
     g_host_err = e.what();
     return -3;

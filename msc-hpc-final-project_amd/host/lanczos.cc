@@ -17,7 +17,7 @@ lanczosDecomp<T>::lanczosDecomp(adjMatrix &adj, const unsigned krylov, T *starti
   const std::size_t n = A.get_n();
   alpha = new T[krylov];
   beta = new T[krylov > 1 ? krylov - 1 : 1];
-  Q = new T[n * krylov];
+  if (!cuda) Q = new T[n * krylov];   // the device path keeps the basis in HBM (ensure_host_basis)
   x = new T[n];
   ans = new T[n];
   x_norm = norm(starting_vec, A.get_n());
@@ -39,7 +39,10 @@ void lanczosDecomp<T>::free_mem() {
   delete[] beta; beta = nullptr;
   delete[] Q; Q = nullptr;
   delete[] x; x = nullptr;
-  if (engine) { lzx_destroy(engine); engine = nullptr; }
+  if (graph) {   // the graph stays with the adjMatrix; only the claim on the resident basis goes
+    if (graph->owner == this) { graph->owner = nullptr; graph->evict = nullptr; }
+    graph.reset();
+  }
 }
 
 // The three-term recurrence with two ping-pong vectors; q_j is copied into column j of the row-major
@@ -73,35 +76,81 @@ void lzx_or_throw(int rc, const char *what) {
 }  // namespace
 
 template <typename T>
+void lanczosDecomp<T>::evict_cb(void *self) {
+  auto *L = static_cast<lanczosDecomp<T> *>(self);
+  try { L->ensure_host_basis(); } catch (...) {}
+  L->graph.reset();
+}
+
+template <typename T>
 void lanczosDecomp<T>::cu_decompose() {
   const unsigned n = A.get_n(), k = krylov_dim;
-  const auto t0 = std::chrono::steady_clock::now();
-  lzx_handle h = nullptr;
-  lzx_or_throw(lzx_create(&h, 0), "lzx_create");
-  engine = h;
-  lzx_or_throw(lzx_set_graph_csr32(h, n, 2 * A.edge_count, A.row_offset, A.col_idx), "lzx_set_graph_csr32");
+  const bool fresh = !A.dev;
+  graph = A.device_graph();   // uploads + reshapes now unless the ingest or an earlier decomposition already did
+  if (graph->owner && graph->owner != this && graph->evict) graph->evict(graph->owner);
+  graph->owner = this;
+  graph->evict = &lanczosDecomp<T>::evict_cb;
+  lzx_handle *hs = graph->ranks.data();
+  const int world = static_cast<int>(graph->ranks.size());
   lzx_graph_info gi;
-  lzx_or_throw(lzx_get_graph_info(h, &gi), "lzx_get_graph_info");
-  const auto t1 = std::chrono::steady_clock::now();
+  lzx_or_throw(lzx_get_graph_info(hs[0], &gi), "lzx_get_graph_info");
   std::cout << "\nUsing " << (gi.sell_padded + gi.n) * 4 + (static_cast<std::uint64_t>(k) + 3) * gi.n * 8
-            << " bytes of HBM for the reshaped graph and " << k << " resident Lanczos vectors\n";
+            << " bytes of HBM for the reshaped graph and " << k << " resident Lanczos vectors on " << world << " GPU handle(s)\n";
 
   lzx_stats st;
+  auto run = [&](const double *x0, double *a, double *b) {
+    if (world == 1) lzx_or_throw(lzx_lanczos_f64(hs[0], x0, k, a, b, nullptr, nullptr, &st), "lzx_lanczos_f64");
+    else lzx_or_throw(lzx_lanczos_f64_local(hs, world, x0, k, a, b, nullptr, nullptr, &st), "lzx_lanczos_f64_local");
+  };
   if constexpr (std::is_same<T, double>::value) {
-    lzx_or_throw(lzx_lanczos_f64(h, x, k, alpha, beta, Q, nullptr, &st), "lzx_lanczos_f64");
+    run(x, alpha, beta);
   } else {
     // The engine computes in fp64 (BASELINE.json north star); a float decomposition is the rounded result.
-    std::vector<double> xd(x, x + n), a(k), b(k > 1 ? k - 1 : 1), Qd(static_cast<std::size_t>(n) * k);
-    lzx_or_throw(lzx_lanczos_f64(h, xd.data(), k, a.data(), b.data(), Qd.data(), nullptr, &st), "lzx_lanczos_f64");
+    std::vector<double> xd(x, x + n), a(k), b(k > 1 ? k - 1 : 1);
+    run(xd.data(), a.data(), b.data());
     std::copy(a.begin(), a.end(), alpha);
     if (k > 1) std::copy(b.begin(), b.begin() + (k - 1), beta);
-    for (std::size_t i = 0; i < Qd.size(); ++i) Q[i] = static_cast<T>(Qd[i]);
   }
-  times.setup_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  times.setup_ms = fresh ? graph->setup_ms : 0.0;
   times.loop_ms = st.loop_ms;
   times.spmv_ms = st.spmv_ms;
   times.vec_ms = st.vec_ms;
+  times.comm_ms = st.comm_ms;
   times.spmv_bytes = st.spmv_bytes;
+  times.gpus = static_cast<unsigned>(world);
+}
+
+template <typename T>
+void lanczosDecomp<T>::ensure_host_basis() {
+  if (Q || !graph) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  const std::size_t n = A.get_n();
+  const unsigned k = krylov_dim;
+  lzx_handle *hs = graph->ranks.data();
+  const int world = static_cast<int>(graph->ranks.size());
+  std::vector<double> a(k), b(k > 1 ? k - 1 : 1);
+  auto fetch = [&](double *Qd) {
+    if (world == 1) lzx_or_throw(lzx_lanczos_fetch_f64(hs[0], k, a.data(), b.data(), Qd), "lzx_lanczos_fetch_f64");
+    else lzx_or_throw(lzx_lanczos_fetch_f64_local(hs, world, k, a.data(), b.data(), Qd), "lzx_lanczos_fetch_f64_local");
+  };
+  Q = new T[n * k];
+  if constexpr (std::is_same<T, double>::value) {
+    fetch(Q);
+  } else {
+    std::vector<double> Qd(n * k);
+    fetch(Qd.data());
+    for (std::size_t i = 0; i < Qd.size(); ++i) Q[i] = static_cast<T>(Qd[i]);
+  }
+  times.fetch_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+template <typename T>
+void lanczosDecomp<T>::device_multout(const double *t, unsigned k, double *out) {
+  if (!graph) throw std::logic_error("lanczosDecomp: the decomposition has no device-resident basis");
+  lzx_handle *hs = graph->ranks.data();
+  const int world = static_cast<int>(graph->ranks.size());
+  if (world == 1) lzx_or_throw(lzx_multout_f64(hs[0], t, k, out), "lzx_multout_f64");
+  else lzx_or_throw(lzx_multout_f64_local(hs, world, t, k, out), "lzx_multout_f64_local");
 }
 
 template <typename T>

@@ -10,7 +10,9 @@
 //   -n N -b M generate a seeded Barabasi-Albert graph of minimum degree M
 //   -v        verbose: print the answer vector
 // Environment: FINAL_SKIP_SERIAL=1 skips the CPU run (large graphs), FINAL_DEVICE_MULTOUT=1 uses the
-// on-device back-projection (parallel-mult-on-card's cu_multOut) for the GPU column.
+// on-device back-projection (parallel-mult-on-card's cu_multOut) for the GPU column; LZX_DEVICES=all | N | a,b,c
+// spreads the device run over several GPUs from this one process (parallel-two-cards' model, any number of cards);
+// LZX_NO_CSR_CACHE=1, LZX_HOST_INGEST=1, LZX_PARSE_THREADS=T steer the loader (host/adjMatrix.h).
 #include <algorithm>
 #include <cstdlib>
 #include <fstream>
@@ -57,13 +59,16 @@ int main(int argc, char **argv) {
                          (filename.size() > 4 && filename.compare(filename.size() - 4, 4, ".mtx") == 0);
     const std::string filepath = is_path ? filename : "../data/" + filename + "/" + filename + ".mtx";
     std::cout << "Going to open file: " << filepath << std::endl;
-    std::ifstream fs(filepath);
-    if (fs.fail()) {
-      std::cerr << "File opening failed: " << filepath << '\n';
-      return 1;
+    {
+      std::ifstream fs(filepath);
+      if (fs.fail()) {
+        std::cerr << "File opening failed: " << filepath << '\n';
+        return 1;
+      }
     }
-    fs >> n >> n >> edges;
-    A = adjMatrix(n, edges, fs);
+    // the reference's `fs >> n >> n >> edges; adjMatrix(n, edges, fs)` (main.cu:62-63) with the path known: binary
+    // side-car cache, several parser threads, device ingest when a GPU is present
+    A = adjMatrix::load(filepath);
     ans_path = is_path ? filepath + ".ans" + std::to_string(krylov_dim) + ".txt"
                        : "../data/" + filename + "/ans" + std::to_string(krylov_dim) + ".txt";
   } else if (deg > 0) {
@@ -79,6 +84,13 @@ int main(int argc, char **argv) {
   krylov_dim = std::max(1u, std::min(krylov_dim, n - 1));  // serial/main.cc:64
   std::cout << "\nTime elapsed to build adjacency matrix with n = " << n << " edges = " << edges << ":\n\t" << build.seconds()
             << " seconds\n\n";
+  {
+    const adjMatrix::loadReport &lr = A.load_report();
+    if (lr.from_cache) std::cout << "\t(binary CSR cache read in " << lr.cache_s << " s)\n\n";
+    else if (!filename.empty())
+      std::cout << "\t(text parse " << lr.parse_s << " s on " << lr.threads << " thread(s); CSR build " << lr.build_s << " s "
+                << (lr.on_device ? "on the GPU: graph already resident" : "on the host") << ")\n\n";
+  }
   std::cout << "Running Lanczos algorithm for krylov_dim " << krylov_dim << "\n\n";
 
   std::vector<double> x(n, 1.0);
@@ -121,7 +133,8 @@ int main(int argc, char **argv) {
   const lanczosTimings &tm = cu_L.timings();
   std::cout << "device loop only: " << tm.loop_ms * 1e-3 << " s (" << krylov_dim / (tm.loop_ms * 1e-3) << " Lanczos iterations/s); "
             << "SpMV " << tm.spmv_ms / krylov_dim << " ms each = " << (tm.spmv_ms > 0 ? tm.spmv_bytes / (tm.spmv_ms / krylov_dim) * 1e-6 : 0.0)
-            << " GB/s of algorithmic bytes; graph upload + reshaping " << tm.setup_ms * 1e-3 << " s\n";
+            << " GB/s of algorithmic bytes on " << tm.gpus << " GPU handle(s); graph upload + reshaping inside the constructor "
+            << tm.setup_ms * 1e-3 << " s; basis download " << tm.fetch_ms * 1e-3 << " s\n";
 
   rule();
   std::cout << "ERROR CHECKING\n";

@@ -31,6 +31,7 @@ void multOut(lanczosDecomp<T> &L, eigenDecomp<T> &E, adjMatrix &, bool Qtrans) {
   const unsigned k = L.get_krylov();
   const std::vector<T> t = small_part(E.eigenvalues, E.eigenvectors, k, L.x_norm);
   if (Qtrans) {
+    L.ensure_host_basis();   // a device decomposition downloads its basis here, on first use
     // ans = sum_j t_j q_j over contiguous vectors: stream each vector once
     for (std::size_t i = 0; i < n; ++i) L.ans[i] = 0;
     for (unsigned j = 0; j < k; ++j) {
@@ -54,8 +55,7 @@ void cu_multOut(lanczosDecomp<T> &L, eigenDecomp<T> &E, adjMatrix &, bool) {
   const unsigned k = L.get_krylov();
   const std::vector<T> t = small_part(E.eigenvalues, E.eigenvectors, k, L.x_norm);
   std::vector<double> td(t.begin(), t.end()), out(L.get_n());
-  if (lzx_multout_f64(L.engine, td.data(), k, out.data()) != LZX_OK)
-    throw std::runtime_error(std::string("lzx_multout_f64: ") + lzx_last_error());
+  L.device_multout(td.data(), k, out.data());
   for (std::size_t i = 0; i < out.size(); ++i) L.ans[i] = static_cast<T>(out[i]);
 }
 
@@ -83,8 +83,7 @@ convergenceReport multOutAdaptive(lanczosDecomp<T> &L, adjMatrix &, unsigned ste
     }
     // y_k = Q_k t
     if (L.on_device()) {
-      if (lzx_multout_f64(L.engine, t.data(), k, cur.data()) != LZX_OK)
-        throw std::runtime_error(std::string("lzx_multout_f64: ") + lzx_last_error());
+      L.device_multout(t.data(), k, cur.data());
     } else if (Qtrans) {
       std::fill(cur.begin(), cur.end(), 0.0);
       for (unsigned j = 0; j < k; ++j) {

@@ -141,13 +141,27 @@ def test_edge_ingest_matches_loader(oracle, engine_factory, tmp_path):
     O.write_mtx(path, 3000, rp, ci)
     tok = np.array(open(path).read().split(), dtype=np.int64)
     pairs = tok[3:].reshape(-1, 2) - 1
-    # duplicates, both orientations and self loops must collapse exactly as the std::set build does
-    src = np.concatenate([pairs[:, 1], pairs[:50, 0], [5, 7]])
-    dst = np.concatenate([pairs[:, 0], pairs[:50, 1], [5, 7]])
+    # duplicates and both orientations must collapse exactly as the std::set build does
+    src = np.concatenate([pairs[:, 1], pairs[:50, 0]])
+    dst = np.concatenate([pairs[:, 0], pairs[:50, 1]])
     eng = engine_factory()
     eng.set_graph_edges(3000, src, dst)
     rp2, ci2 = eng.get_graph_csr()
     assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci)
+    # a self loop is one diagonal entry there (both inserted keys are equal): compare with the loader on such a file
+    with open(path, "a") as f:
+        f.write("6 6\n8 8\n")
+    lines = open(path).read().split("\n")
+    hdr = lines[0].split()
+    lines[0] = f"{hdr[0]} {hdr[1]} {int(hdr[2]) + 2}"
+    open(path, "w").write("\n".join(lines))
+    _, _, rp3, ci3 = O.load_mtx(path)
+    assert len(ci3) == len(ci) + 2
+    eng.set_graph_edges(3000, np.concatenate([src, [5, 7]]), np.concatenate([dst, [5, 7]]))
+    rp4, ci4 = eng.get_graph_csr()
+    assert np.array_equal(rp4, rp3) and np.array_equal(ci4, ci3)
+    y = eng.spmv(np.arange(3000, dtype=np.float64))
+    assert np.allclose(y, O.spmv(rp3, ci3, np.arange(3000, dtype=np.float64)), rtol=1e-13)
     eng.close()
 
 

@@ -29,6 +29,8 @@ def host(pkg):
     H.host_adaptive_file.restype = ctypes.c_long
     H.host_gen_csr.argtypes = [ctypes.c_char, ctypes.c_uint, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_ulonglong, _u32p, _u32p, ctypes.c_uint]
     H.host_gen_csr.restype = ctypes.c_long
+    H.host_load_path.argtypes = [ctypes.c_char_p, _u32p, _u32p, ctypes.c_uint, _u32p]
+    H.host_load_path.restype = ctypes.c_long
     return H
 
 
@@ -126,3 +128,60 @@ def test_convergence_monitor_cpu(host, tmp_path):
     assert ch[0] == 1.0 and np.all(np.diff(ch[1:m]) < 0) and ch[m - 1] <= 1e-12
     assert used.value == ks[m - 1] and used.value < 40          # stopped early
     assert np.abs(ans - g["expm_ref"]).max() <= 1e-10 * np.abs(g["expm_ref"]).max()
+
+
+def _load_path(host, path, n, cap):
+    ro = np.zeros(n + 1, dtype=np.uint32)
+    ci = np.zeros(cap, dtype=np.uint32)
+    info = np.zeros(4, dtype=np.uint32)
+    edges = host.host_load_path(path.encode(), p(ro, _u32p), p(ci, _u32p), cap, p(info, _u32p))
+    assert edges >= 0, host.host_last_error()
+    return ro, ci[:info[3]], info
+
+
+def test_parallel_parser_and_cache_match_the_sequential_loader(host, oracle, tmp_path, monkeypatch):
+    """N1: the text is parsed by several threads and a binary side-car caches the CSR; both must give exactly the CSR
+    of the one-thread loader (which the golden fixtures pin to the reference's std::set build)."""
+    O = oracle
+    n = 60000
+    rp, ci = O.gen_rmat(16, n, 400000, 99)
+    path = str(tmp_path / "big.mtx")
+    O.write_mtx(path, n, rp, ci)
+    assert os.path.getsize(path) > (1 << 20)          # large enough for the parser to split it
+    monkeypatch.setenv("LZX_NO_CSR_CACHE", "1")
+    monkeypatch.setenv("LZX_PARSE_THREADS", "1")
+    ro1, ci1, info1 = _load_path(host, path, n, len(ci) + 8)
+    assert info1[0] == 0 and info1[2] == 1
+    assert np.array_equal(ro1, rp.astype(np.uint32)) and np.array_equal(ci1, ci)
+    monkeypatch.setenv("LZX_PARSE_THREADS", "7")
+    ro7, ci7, info7 = _load_path(host, path, n, len(ci) + 8)
+    assert info7[2] == 7 and np.array_equal(ro7, ro1) and np.array_equal(ci7, ci1)
+    assert not os.path.exists(path + ".lzxcsr")
+    monkeypatch.delenv("LZX_NO_CSR_CACHE")
+    _, _, a = _load_path(host, path, n, len(ci) + 8)   # parses and writes the side-car
+    assert a[0] == 0 and os.path.exists(path + ".lzxcsr")
+    roc, cic, b = _load_path(host, path, n, len(ci) + 8)
+    assert b[0] == 1 and np.array_equal(roc, ro1) and np.array_equal(cic, ci1)
+    # a changed text file invalidates the side-car (size + mtime are part of its header)
+    with open(path, "a") as f:
+        f.write("\n")
+    _, _, c = _load_path(host, path, n, len(ci) + 8)
+    assert c[0] == 0
+
+
+def test_self_loop_line_is_one_diagonal_entry(host, oracle, tmp_path, monkeypatch):
+    """A `r r` line: the reference's std::set holds the key once, so the row gets ONE diagonal entry and
+    row_offset[n] is odd (2 * edge_count would be one short / one over: ADVICE r1)."""
+    monkeypatch.setenv("LZX_NO_CSR_CACHE", "1")
+    path = str(tmp_path / "loop.mtx")
+    write_pairs(path, 6, np.array([[2, 1], [3, 3], [5, 4], [6, 1]]))
+    ro, ci, info = _load_path(host, path, 6, 16)
+    assert info[3] == 7 and ro[-1] == 7
+    assert list(ci[ro[2]:ro[3]]) == [2]
+    n, e, ro_ref, ci_ref = oracle.load_mtx(path)
+    assert np.array_equal(ro, ro_ref.astype(np.uint32)) and np.array_equal(ci, ci_ref)
+    ans = np.zeros(6)
+    alpha, beta = np.zeros(3), np.zeros(3)
+    rc = host.host_expm_file(path.encode(), 3, 0, 0, p(ans, _f64p), 6, p(alpha, _f64p), p(beta, _f64p))
+    assert rc == 6, host.host_last_error()
+    assert np.isfinite(ans).all()

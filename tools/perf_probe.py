@@ -37,6 +37,8 @@ if __name__ == "__main__":
     sets = [a[1:] for a in sys.argv[1:] if a.startswith("@")]
     opts = [dict(), dict(hub_entries=0), dict(hub_entries=16384, wgs_per_cu=1), dict(hub_entries=4096),
             dict(nt_index_loads=1), dict(hub_entries=0, nt_index_loads=1), dict(wgs_per_cu=1), dict(hub_entries=0, wgs_per_cu=4)]
+    if "persist" in sets:
+        opts = [dict(), dict(pb_persistent=0), dict(), dict(pb_persistent=0)]
     if "plain" in sets:
         opts = [dict(), dict(wgs_per_cu=3), dict(wgs_per_cu=4), dict(long_row=192), dict(long_row=96)]
     if "pbx" in sets:
