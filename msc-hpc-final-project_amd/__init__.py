@@ -13,6 +13,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblzx.so")
+# the same code built with -DLZX_DEBUG_KNOBS: experiment knobs, test hooks, ablation switches (Makefile, `make debug`)
+DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
+# what the product library's lzx_set_option knows (include/lzx.h); any other option name selects the debug library
+PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "lazy_normalisation", "timing_marks_every")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -80,24 +84,34 @@ SYMBOLS = [
 ]
 
 _LIB = None
+_DBG_LIB = None
 
 
 class LzxError(RuntimeError):
     pass
 
 
-def lib() -> ctypes.CDLL:
-    """Load liblzx.so; raises if it has not been built (no fallback)."""
-    global _LIB
+def _load(path: str, mode: int) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise LzxError(f"{path} is missing: run __graft_entry__.build() (make -C {_HERE})")
+    L = ctypes.CDLL(path, mode=mode)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def lib(debug: bool = False) -> ctypes.CDLL:
+    """liblzx.so (the product), or liblzx_dbg.so when debug-only options are wanted; raises if it has not been
+    built (no fallback).  Both are linked -Bsymbolic, so they can be loaded side by side."""
+    global _LIB, _DBG_LIB
+    if debug:
+        if _DBG_LIB is None:
+            _DBG_LIB = _load(DBG_LIB_PATH, ctypes.RTLD_LOCAL)
+        return _DBG_LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise LzxError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C {_HERE})")
-        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-        for name, res, args in SYMBOLS:
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _LIB = L
+        _LIB = _load(LIB_PATH, ctypes.RTLD_GLOBAL)
     return _LIB
 
 
@@ -105,9 +119,9 @@ def _p(a, ty):
     return a.ctypes.data_as(ty)
 
 
-def _check(rc: int, what: str):
+def _check(rc: int, what: str, L=None):
     if rc != 0:
-        raise LzxError(f"{what} failed ({rc}): {lib().lzx_last_error().decode(errors='replace')}")
+        raise LzxError(f"{what} failed ({rc}): {(L or lib()).lzx_last_error().decode(errors='replace')}")
 
 
 def rmat_thresholds(a=0.57, b=0.19, c=0.19):
@@ -119,17 +133,18 @@ class Engine:
 
     def __init__(self, device: int = 0, **options):
         self.h = ctypes.c_void_p()
-        _check(lib().lzx_create(ctypes.byref(self.h), device), "lzx_create")
+        self.L = lib(debug=any(k not in PRODUCT_OPTIONS for k in options))
+        _check(self.L.lzx_create(ctypes.byref(self.h), device), "lzx_create", self.L)
         for k, v in options.items():
             self.set_option(k, v)
         self.n = 0
 
     def set_option(self, name: str, value: int):
-        _check(lib().lzx_set_option(self.h, name.encode(), int(value)), f"lzx_set_option({name})")
+        _check(self.L.lzx_set_option(self.h, name.encode(), int(value)), f"lzx_set_option({name})", self.L)
 
     def close(self):
         if self.h:
-            lib().lzx_destroy(self.h)
+            self.L.lzx_destroy(self.h)
             self.h = ctypes.c_void_p()
 
     def __del__(self):
@@ -147,7 +162,7 @@ class Engine:
 
     def comm_init_rank(self, uid: np.ndarray, rank: int, world: int):
         uid = np.ascontiguousarray(uid, dtype=np.uint8)
-        _check(lib().lzx_comm_init_rank(self.h, _p(uid, _u8p), rank, world), "lzx_comm_init_rank")
+        _check(self.L.lzx_comm_init_rank(self.h, _p(uid, _u8p), rank, world), "lzx_comm_init_rank", self.L)
 
     # ---- graph ----
     def set_graph_csr(self, row_ptr, col_idx):
@@ -155,7 +170,7 @@ class Engine:
         col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
         n, nnz = len(row_ptr) - 1, len(col_idx)
         ci = col_idx if nnz else np.zeros(1, dtype=np.uint32)
-        _check(lib().lzx_set_graph_csr(self.h, n, nnz, _p(row_ptr, _u64p), _p(ci, _u32p)), "lzx_set_graph_csr")
+        _check(self.L.lzx_set_graph_csr(self.h, n, nnz, _p(row_ptr, _u64p), _p(ci, _u32p)), "lzx_set_graph_csr", self.L)
         self.n = n
 
     def set_graph_csr32(self, row_ptr, col_idx):
@@ -163,7 +178,7 @@ class Engine:
         col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
         n, nnz = len(row_ptr) - 1, len(col_idx)
         ci = col_idx if nnz else np.zeros(1, dtype=np.uint32)
-        _check(lib().lzx_set_graph_csr32(self.h, n, nnz, _p(row_ptr, _u32p), _p(ci, _u32p)), "lzx_set_graph_csr32")
+        _check(self.L.lzx_set_graph_csr32(self.h, n, nnz, _p(row_ptr, _u32p), _p(ci, _u32p)), "lzx_set_graph_csr32", self.L)
         self.n = n
 
     def set_graph_edges(self, n, src, dst):
@@ -172,28 +187,28 @@ class Engine:
         assert len(src) == len(dst)
         s = src if len(src) else np.zeros(1, dtype=np.uint32)
         d = dst if len(dst) else np.zeros(1, dtype=np.uint32)
-        _check(lib().lzx_set_graph_edges(self.h, n, len(src), _p(s, _u32p), _p(d, _u32p)), "lzx_set_graph_edges")
+        _check(self.L.lzx_set_graph_edges(self.h, n, len(src), _p(s, _u32p), _p(d, _u32p)), "lzx_set_graph_edges", self.L)
         self.n = n
 
     def gen_er(self, n, draws, seed):
-        _check(lib().lzx_gen_graph(self.h, 0, 0, n, draws, seed, 0, 0, 0), "lzx_gen_graph(er)")
+        _check(self.L.lzx_gen_graph(self.h, 0, 0, n, draws, seed, 0, 0, 0), "lzx_gen_graph(er)", self.L)
         self.n = n
 
     def gen_rmat(self, scale, n, draws, seed, a=0.57, b=0.19, c=0.19):
         ta, tab, tabc = rmat_thresholds(a, b, c)
-        _check(lib().lzx_gen_graph(self.h, 1, scale, n, draws, seed, ta, tab, tabc), "lzx_gen_graph(rmat)")
+        _check(self.L.lzx_gen_graph(self.h, 1, scale, n, draws, seed, ta, tab, tabc), "lzx_gen_graph(rmat)", self.L)
         self.n = n
 
     def info(self) -> dict:
         gi = LzxGraphInfo()
-        _check(lib().lzx_get_graph_info(self.h, ctypes.byref(gi)), "lzx_get_graph_info")
+        _check(self.L.lzx_get_graph_info(self.h, ctypes.byref(gi)), "lzx_get_graph_info", self.L)
         return gi.as_dict()
 
     def get_graph_csr(self):
         gi = self.info()
         rp = np.empty(gi["n"] + 1, dtype=np.uint64)
         ci = np.empty(max(gi["nnz"], 1), dtype=np.uint32)
-        _check(lib().lzx_get_graph_csr(self.h, _p(rp, _u64p), _p(ci, _u32p)), "lzx_get_graph_csr")
+        _check(self.L.lzx_get_graph_csr(self.h, _p(rp, _u64p), _p(ci, _u32p)), "lzx_get_graph_csr", self.L)
         return rp, ci[:gi["nnz"]]
 
     # ---- hot path ----
@@ -201,7 +216,7 @@ class Engine:
         x = np.ascontiguousarray(x, dtype=np.float64)
         assert len(x) == self.n
         y = np.empty(self.n)
-        _check(lib().lzx_spmv_f64(self.h, _p(x, _f64p), _p(y, _f64p)), "lzx_spmv_f64")
+        _check(self.L.lzx_spmv_f64(self.h, _p(x, _f64p), _p(y, _f64p)), "lzx_spmv_f64", self.L)
         return y
 
     def lanczos(self, x0, k: int, want_q: bool = True):
@@ -213,7 +228,7 @@ class Engine:
         Q = np.empty((k, self.n)) if want_q else None
         xn = ctypes.c_double()
         st = LzxStats()
-        _check(lib().lzx_lanczos_f64(self.h, _p(x0, _f64p), k, _p(alpha, _f64p), _p(beta, _f64p),
+        _check(self.L.lzx_lanczos_f64(self.h, _p(x0, _f64p), k, _p(alpha, _f64p), _p(beta, _f64p),
                                      _p(Q, _f64p) if want_q else None, ctypes.byref(xn), ctypes.byref(st)),
                "lzx_lanczos_f64")
         return alpha, beta[:k - 1], Q, xn.value, st.as_dict()
@@ -222,39 +237,39 @@ class Engine:
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         assert len(x0) == self.n
         xn = ctypes.c_double()
-        _check(lib().lzx_lanczos_prepare_f64(self.h, _p(x0, _f64p), k, ctypes.byref(xn)), "lzx_lanczos_prepare_f64")
+        _check(self.L.lzx_lanczos_prepare_f64(self.h, _p(x0, _f64p), k, ctypes.byref(xn)), "lzx_lanczos_prepare_f64", self.L)
         return xn.value
 
     def lanczos_run(self) -> dict:
         st = LzxStats()
-        _check(lib().lzx_lanczos_run(self.h, ctypes.byref(st)), "lzx_lanczos_run")
+        _check(self.L.lzx_lanczos_run(self.h, ctypes.byref(st)), "lzx_lanczos_run", self.L)
         return st.as_dict()
 
     def lanczos_fetch(self, k: int, want_q: bool = False):
         alpha = np.zeros(k)
         beta = np.zeros(max(k - 1, 1))
         Q = np.empty((k, self.n)) if want_q else None
-        _check(lib().lzx_lanczos_fetch_f64(self.h, k, _p(alpha, _f64p), _p(beta, _f64p),
-                                           _p(Q, _f64p) if want_q else None), "lzx_lanczos_fetch_f64")
+        _check(self.L.lzx_lanczos_fetch_f64(self.h, k, _p(alpha, _f64p), _p(beta, _f64p),
+                                           _p(Q, _f64p) if want_q else None), "lzx_lanczos_fetch_f64", self.L)
         return alpha, beta[:k - 1], Q
 
     def sync(self):
-        _check(lib().lzx_sync(self.h), "lzx_sync")
+        _check(self.L.lzx_sync(self.h), "lzx_sync", self.L)
 
     def multout(self, t):
         t = np.ascontiguousarray(t, dtype=np.float64)
         ans = np.empty(self.n)
-        _check(lib().lzx_multout_f64(self.h, _p(t, _f64p), len(t), _p(ans, _f64p)), "lzx_multout_f64")
+        _check(self.L.lzx_multout_f64(self.h, _p(t, _f64p), len(t), _p(ans, _f64p)), "lzx_multout_f64", self.L)
         return ans
 
     def bench_stream(self, nbytes: int = 1 << 30, reps: int = 5):
         rd, cp = ctypes.c_double(), ctypes.c_double()
-        _check(lib().lzx_bench_stream(self.h, nbytes, reps, ctypes.byref(rd), ctypes.byref(cp)), "lzx_bench_stream")
+        _check(self.L.lzx_bench_stream(self.h, nbytes, reps, ctypes.byref(rd), ctypes.byref(cp)), "lzx_bench_stream", self.L)
         return rd.value, cp.value
 
     def bench_spmv(self, reps: int = 20):
         avg, mn = ctypes.c_double(), ctypes.c_double()
-        _check(lib().lzx_bench_spmv(self.h, reps, ctypes.byref(avg), ctypes.byref(mn)), "lzx_bench_spmv")
+        _check(self.L.lzx_bench_spmv(self.h, reps, ctypes.byref(avg), ctypes.byref(mn)), "lzx_bench_spmv", self.L)
         return avg.value, mn.value
 
 
@@ -263,9 +278,10 @@ class LocalGroup:
 
     def __init__(self, devices, **options):
         self.engines = [Engine(d, **options) for d in devices]
+        self.L = self.engines[0].L
         self.world = len(devices)
         self.arr = (ctypes.c_void_p * self.world)(*[e.h for e in self.engines])
-        _check(lib().lzx_comm_init_local(self.arr, self.world), "lzx_comm_init_local")
+        _check(self.L.lzx_comm_init_local(self.arr, self.world), "lzx_comm_init_local", self.L)
         self.n = 0
 
     def set_graph_csr(self, row_ptr, col_idx):
@@ -276,7 +292,7 @@ class LocalGroup:
     def spmv(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.empty(self.n)
-        _check(lib().lzx_spmv_f64_local(self.arr, self.world, _p(x, _f64p), _p(y, _f64p)), "lzx_spmv_f64_local")
+        _check(self.L.lzx_spmv_f64_local(self.arr, self.world, _p(x, _f64p), _p(y, _f64p)), "lzx_spmv_f64_local", self.L)
         return y
 
     def lanczos(self, x0, k: int, want_q: bool = True):
@@ -286,16 +302,15 @@ class LocalGroup:
         Q = np.empty((k, self.n)) if want_q else None
         xn = ctypes.c_double()
         st = LzxStats()
-        _check(lib().lzx_lanczos_f64_local(self.arr, self.world, _p(x0, _f64p), k, _p(alpha, _f64p),
+        _check(self.L.lzx_lanczos_f64_local(self.arr, self.world, _p(x0, _f64p), k, _p(alpha, _f64p),
                                            _p(beta, _f64p), _p(Q, _f64p) if want_q else None,
-                                           ctypes.byref(xn), ctypes.byref(st)), "lzx_lanczos_f64_local")
+                                           ctypes.byref(xn), ctypes.byref(st)), "lzx_lanczos_f64_local", self.L)
         return alpha, beta[:k - 1], Q, xn.value, st.as_dict()
 
     def multout(self, t):
         t = np.ascontiguousarray(t, dtype=np.float64)
         ans = np.empty(self.n)
-        _check(lib().lzx_multout_f64_local(self.arr, self.world, _p(t, _f64p), len(t), _p(ans, _f64p)),
-               "lzx_multout_f64_local")
+        _check(self.L.lzx_multout_f64_local(self.arr, self.world, _p(t, _f64p), len(t), _p(ans, _f64p)), "lzx_multout_f64_local", self.L)
         return ans
 
     def close(self):

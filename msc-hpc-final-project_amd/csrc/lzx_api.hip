@@ -5,6 +5,7 @@
 // and the download of alpha/beta is enqueued on HIP streams without a host synchronisation; the
 // scalars alpha_j / beta_j never leave the device (as in the reference, where later kernels read
 // *alpha_d: parallel-final/lib/cu_lanczos.cu:108,113,123).
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -95,11 +96,16 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     if (!c || !name) LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: bad argument");
     if (c->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "options must be set before the graph is handed over");
     if (!strcmp(name, "hub_entries")) c->hub_opt = value;
+    else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
+    else if (!strcmp(name, "overlap_exchange")) c->overlap_opt = value;
+    else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
+    else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
+#ifdef LZX_DEBUG_KNOBS
+    // experiment knobs and test hooks: only in liblzx_dbg.so (make debug), which tests/ and tools/perf_probe.py load
+    // when they ask for one of these; the product library does not know the names
     else if (!strcmp(name, "wgs_per_cu")) c->wgs_per_cu_opt = value;
     else if (!strcmp(name, "nt_index_loads")) c->nt_opt = value;
     else if (!strcmp(name, "long_row")) c->long_row_opt = value;
-    else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
-    else if (!strcmp(name, "overlap_exchange")) c->overlap_opt = value;
     else if (!strcmp(name, "pb_target")) c->pb_target_opt = value;
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "pb_reduce")) c->pb_reduce_opt = value;
@@ -108,10 +114,11 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "pb_persistent")) c->pb_persist_opt = value;
-    else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
+    else if (!strcmp(name, "pb_stamps")) c->pb_stamps_opt = value;
+    else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
-    else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
+#endif
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
 }
@@ -699,10 +706,12 @@ __global__ void __launch_bounds__(256) k_stream_read(const double2 *p, u64 n16, 
 {
     const u64 nthreads = (u64)gridDim.x * blockDim.x;
     double acc = 0.0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += nthreads) {
-        const double2 c = p[i];
-        acc += c.x + c.y;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + nthreads < n16; i += 2 * nthreads) {   // two 16-byte loads in flight per lane
+        const double2 c = p[i], d = p[i + nthreads];
+        acc += (c.x + c.y) + (d.x + d.y);
     }
+    if (i < n16) acc += p[i].x + p[i].y;
     if (acc == 1.2345e-300) out[0] = acc;   // keeps the loads alive
 }
 __global__ void __launch_bounds__(256) k_stream_copy(const double2 *src, double2 *dst, u64 n16)
@@ -771,6 +780,7 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
     }
     *avg_ms = total / reps;
     if (min_ms) *min_ms = best;
+#ifdef LZX_DEBUG_KNOBS
     if (getenv("LZX_TRACE_SPMV")) {
         // one more SpMV with marks between its kernels: hub/body, split-row finish, scatter, gather (+finish)
         for (auto &ev : c->trace_ev)
@@ -790,6 +800,40 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
         }
         fprintf(stderr, "[lzx trace] k_spmv %.4f ms  long_finish %.4f ms  pb_scatter %.4f ms  pb_gather(+finish) %.4f ms\n",
                 t[0], t[1], t[2], t[3]);
+        if (c->d_pb_stamps) {
+            // per-workgroup time lines of the persistent passes (100 MHz ticks): when did workgroups start and end
+            std::vector<unsigned long long> h(3 * 4096);
+            LZX_HIP(hipMemcpy(h.data(), c->d_pb_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+            const char *nm[3] = {"scatter chunk 0", "scatter chunk 1", "gather"};
+            for (int q = 0; q < 3; ++q) {
+                std::vector<double> st, en, busy;
+                unsigned long long t0 = ~0ull;
+                u64 units = 0, restaged = 0;
+                for (int w = 0; w < 1024; ++w) {
+                    const unsigned long long *r = &h[(size_t)q * 4096 + 4 * w];
+                    if (r[1] == 0) continue;
+                    t0 = std::min(t0, r[0]);
+                }
+                for (int w = 0; w < 1024; ++w) {
+                    const unsigned long long *r = &h[(size_t)q * 4096 + 4 * w];
+                    if (r[1] == 0) continue;
+                    st.push_back((r[0] - t0) * 0.01);
+                    en.push_back((r[1] - t0) * 0.01);
+                    busy.push_back((r[1] - r[0]) * 0.01);
+                    units += r[2];
+                    restaged += r[3];
+                }
+                if (en.empty()) continue;
+                std::sort(st.begin(), st.end());
+                std::sort(en.begin(), en.end());
+                std::sort(busy.begin(), busy.end());
+                auto pct = [](const std::vector<double> &v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+                fprintf(stderr, "[lzx stamps] %s: %zu workgroups, %llu units, %llu restagings | start us: max %.1f | end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | busy us: min %.1f p50 %.1f max %.1f\n",
+                        nm[q], en.size(), (unsigned long long)units, (unsigned long long)restaged, st.back(), en.front(), pct(en, 0.1),
+                        pct(en, 0.5), pct(en, 0.9), en.back(), busy.front(), pct(busy, 0.5), busy.back());
+            }
+        }
     }
+#endif
     return LZX_OK;
 }

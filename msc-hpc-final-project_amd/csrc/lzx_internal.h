@@ -165,10 +165,15 @@ struct lzx_ctx {
     u32 *d_pb_multi = nullptr;         // [pb_n_multi][4] row, first slot, items, slot stride: rows of bands cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows
     uint8_t *d_pb_long_multi = nullptr; // [n_long64] 1: the split row is also listed in d_pb_multi
-    u32 *d_pb_items2 = nullptr;        // [pb_n_items][8] the persistent gather pass's records, largest item first:
+    u32 *d_pb_items2 = nullptr;        // [pb_n_items][8] the persistent gather pass's records, workgroup by workgroup:
                                        // begin, end, first row, rows, slots per row, total slot or ~0, 0, 0
-    u32 *d_pb_queue = nullptr;         // [4] ticket counters of the persistent passes: scatter chunk 0, chunk 1, gather
+    u32 *d_pb_wg_begin = nullptr;      // [pb_gather_grid + 1] first record of each gather workgroup's fixed list
+    u32 *d_pb_queue = nullptr;         // [4] ticket counters of the persistent scatter pass: chunk 0, chunk 1
     u32 pb_qbase[4] = {0, 0, 0, 0};    // value each counter will have when its next launch starts
+    unsigned long long *d_pb_stamps = nullptr;   // [3][4096] debug library, option pb_stamps: per-workgroup start / end ticks
+    int64_t pb_stamps_opt = -1;
+    int64_t pb_gwaves_opt = -1;        // wavefronts per gather workgroup (debug knob): 8 (default) or 4
+    u32 pb_gather_block = 512;
     int64_t pb_persist_opt = -1;       // persistent passes: -1/1 on, 0 = one workgroup per unit / static item lists
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;

@@ -35,6 +35,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <queue>
+#include <utility>
 
 #include "lzx_internal.h"
 
@@ -671,8 +673,12 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
 template <u32 CB>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol,
-              const u32 *q_dst, const double *__restrict__ x, u64 xlen, double *val)
+              const u32 *q_dst, const double *__restrict__ x, u64 xlen, double *val, unsigned long long *stamps)
 {
+    // stamps (debug library only, else null): [4 * workgroup] start, end (100 MHz ticks), units done, restagings
+    unsigned long long t_start = 0;
+    u32 n_done = 0, n_restaged = 0;
+    if (stamps) t_start = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) double tile[];   // CB staged values + a zero for padding
     u32 *tick = reinterpret_cast<u32 *>(tile + CB + 2 + 16 * 66);   // [2]
     const u32 lane = threadIdx.x & 63;
@@ -817,7 +823,9 @@ k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *
         }
         if (threadIdx.x == 0) tick[0] = t2;
         __syncthreads();                      // every wavefront is done with the band in LDS
+        ++n_done;
         if (!have_next) break;
+        n_restaged += restage ? 1u : 0u;
         if (restage) {
 #pragma unroll
             for (u32 u = 0; u < PRE; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = pre[u];
@@ -828,56 +836,72 @@ k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *
         nxt = t2_all;
         band = band_next;
     }
+    if (stamps && threadIdx.x == 0) {
+        stamps[4 * blockIdx.x] = t_start;
+        stamps[4 * blockIdx.x + 1] = wall_clock64();
+        stamps[4 * blockIdx.x + 2] = n_done;
+        stamps[4 * blockIdx.x + 3] = n_restaged;
+    }
 }
 
+// The gather pass keeps a FIXED item list per workgroup instead of tickets (lists balanced by the host, longest item
+// first): which workgroup adds an item's share of alpha = v . q must not change from run to run, or alpha would not be
+// reproducible bit for bit.  The next record is fetched while the current item streams, the rows of the fold ahead of it.
 // item record (two uint4): {begin, end, first row, rows} {slots per row, total slot or ~0, -, -}
-__global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
-k_pb_gather2(const uint4 *items2, u32 n_items, u32 *queue, u32 qbase, const uint16_t *lslot, const double *val, double *v,
-             const double *__restrict__ q_loc, double *part, double *partials)
+template <u32 BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_pb_gather2(const uint4 *items2, const u32 *wg_begin, const uint16_t *lslot, const double *val, double *v,
+             const double *__restrict__ q_loc, double *part, double *partials, unsigned long long *stamps)
 {
+    unsigned long long t_start = 0;
+    if (stamps) t_start = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
+    constexpr u32 WAVES = BLOCK / 64;
+    constexpr u32 FOLD = LZX_PB_RB / BLOCK;   // rows of the fold per thread
     constexpr u32 TILE = LZX_PB_RB + 8;
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     double *ytile = lds + (size_t)wv * TILE;
     double *wsum = lds + (size_t)WAVES * TILE;
-    u32 *tick = reinterpret_cast<u32 *>(wsum + WAVES);
     double dot = 0.0;
-    if (tid == 0) tick[0] = atomicAdd(queue, 1u) - qbase;
-    __syncthreads();
-    u32 it = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
+    u32 it = (u32)__builtin_amdgcn_readfirstlane((int)wg_begin[blockIdx.x]);
+    const u32 n_items = (u32)__builtin_amdgcn_readfirstlane((int)wg_begin[blockIdx.x + 1]);
     uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
     if (it < n_items) {
         r0 = items2[2 * (size_t)it];
         r1 = items2[2 * (size_t)it + 1];
     }
-    __syncthreads();                          // tick[0] is free again
     while (it < n_items) {
         const u32 beg = (u32)__builtin_amdgcn_readfirstlane((int)r0.x), end = (u32)__builtin_amdgcn_readfirstlane((int)r0.y);
         const u32 row0 = (u32)__builtin_amdgcn_readfirstlane((int)r0.z), rows = (u32)__builtin_amdgcn_readfirstlane((int)r0.w);
         const u32 rep = (u32)__builtin_amdgcn_readfirstlane((int)r1.x), slot = (u32)__builtin_amdgcn_readfirstlane((int)r1.y);
-        u32 tn = 0xffffffffu;
-        if (tid == 0) tn = atomicAdd(queue, 1u) - qbase;     // the next ticket travels while this item streams
+        const u32 nx = it + 1;
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+        if (nx < n_items) {                                    // the next record travels while this item streams
+            n0 = items2[2 * (size_t)nx];
+            n1 = items2[2 * (size_t)nx + 1];
+        }
         double acc = 0.0;                                      // rows == 1
-        double vv[2] = {0.0, 0.0}, qq[2] = {0.0, 0.0};        // this thread's rows of the fold, fetched ahead
+        double vv[FOLD], qq[FOLD];
+#pragma unroll
+        for (u32 u = 0; u < FOLD; ++u) vv[u] = qq[u] = 0.0;        // this thread's rows of the fold, fetched ahead
         if (rows == 1) {
             u32 i = beg + tid;
-            for (; i + 7 * LZX_PB_GATHER_BLOCK < end; i += 8 * LZX_PB_GATHER_BLOCK) {
+            for (; i + 7 * BLOCK < end; i += 8 * BLOCK) {
                 double a[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] = val[i + u * LZX_PB_GATHER_BLOCK];
+                for (int u = 0; u < 8; ++u) a[u] = val[i + u * BLOCK];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += a[u];
             }
-            for (; i < end; i += LZX_PB_GATHER_BLOCK) acc += val[i];
+            for (; i < end; i += BLOCK) acc += val[i];
             acc = wave_sum_pb(acc);
             if (lane == 0) wsum[wv] = acc;
         } else {
             if (slot == 0xffffffffu) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
+                for (u32 u = 0; u < FOLD; ++u) {
+                    const u32 j = tid + u * BLOCK;
                     if (j < rows) {
                         vv[u] = v[row0 + j];
                         qq[u] = q_loc[row0 + j];
@@ -943,14 +967,7 @@ k_pb_gather2(const uint4 *items2, u32 n_items, u32 *queue, u32 qbase, const uint
                 atomicAdd(&ytile[ts[1]], tv[1]);
             }
         }
-        if (tid == 0) tick[0] = tn;
         __syncthreads();
-        const u32 nx = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
-        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
-        if (nx < n_items) {                    // in flight during the fold
-            n0 = items2[2 * (size_t)nx];
-            n1 = items2[2 * (size_t)nx + 1];
-        }
         if (rows == 1) {
             if (tid == 0) {
                 double t = 0.0;
@@ -964,8 +981,8 @@ k_pb_gather2(const uint4 *items2, u32 n_items, u32 *queue, u32 qbase, const uint
             }
         } else if (slot == 0xffffffffu) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
+            for (u32 u = 0; u < FOLD; ++u) {
+                const u32 j = tid + u * BLOCK;
                 if (j < rows) {
                     double y = 0.0;
                     for (u32 w = 0; w < WAVES; ++w)
@@ -975,14 +992,14 @@ k_pb_gather2(const uint4 *items2, u32 n_items, u32 *queue, u32 qbase, const uint
                 }
             }
         } else {
-            for (u32 j = tid; j < rows; j += LZX_PB_GATHER_BLOCK) {
+            for (u32 j = tid; j < rows; j += BLOCK) {
                 double y = 0.0;
                 for (u32 w = 0; w < WAVES; ++w)
                     for (u32 t = 0; t < rep; ++t) y += lds[(size_t)w * TILE + j * rep + t];
                 part[slot + j] = y;
             }
         }
-        __syncthreads();                      // tiles, wsum and tick are free
+        __syncthreads();                      // tiles and wsum are free
         it = nx;
         r0 = n0;
         r1 = n1;
@@ -995,6 +1012,12 @@ k_pb_gather2(const uint4 *items2, u32 n_items, u32 *queue, u32 qbase, const uint
         double s = 0.0;
         for (u32 i = 0; i < WAVES; ++i) s += wsum[i];
         partials[blockIdx.x] = s;
+        if (stamps) {
+            stamps[4 * blockIdx.x] = t_start;
+            stamps[4 * blockIdx.x + 1] = wall_clock64();
+            stamps[4 * blockIdx.x + 2] = wg_begin[blockIdx.x + 1] - wg_begin[blockIdx.x];
+            stamps[4 * blockIdx.x + 3] = 0;
+        }
     }
 }
 
@@ -1024,6 +1047,8 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_rep);
     pb_free(c->d_pb_items);
     pb_free(c->d_pb_items2);
+    pb_free(c->d_pb_wg_begin);
+    pb_free(c->d_pb_stamps);
     pb_free(c->d_pb_queue);
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
@@ -1314,6 +1339,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         LZX_TRY(pb_download(st, d_band_pos, (size_t)nr + 1, rstart));
         ar.drop(d_rstart); ar.drop(d_band_pos);
     }
+#ifdef LZX_DEBUG_KNOBS
     if (getenv("LZX_PB_STATS")) {   // run-length histogram (entries per class), for DESIGN.md
         std::vector<u32> rs;
         LZX_TRY(pb_download(st, d_runstart, nruns, rs));
@@ -1329,6 +1355,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             fprintf(stderr, "[lzx pb stats] runs of %u..%u entries: %llu runs, %llu entries (%.1f %%)\n", 1u << b, (2u << b) - 1,
                     (unsigned long long)cnt[b], (unsigned long long)cls[b], 100.0 * cls[b] / (double)total);
     }
+#endif
     {   // entries of the reduced runs (reporting only)
         std::vector<u32> rs;
         std::vector<uint8_t> fm(nruns);
@@ -1447,22 +1474,50 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     }
     c->pb_n_items = (u32)(items.size() / 4);
     c->pb_n_multi = (u32)(multi.size() / 4);
-    {   // records of the persistent gather pass: everything an item needs in one place, largest item first (tickets are
-        // drawn in this order, so the long items start early and the short ones even out the end)
+    // one item per workgroup at a time, two workgroups per CU
+    // 16 wavefronts per CU (their private y tiles fill the LDS): two workgroups of eight, or four of four
+    c->pb_gather_block = c->pb_gwaves_opt == 4 ? 256u : 512u;
+    c->pb_gather_grid = std::min<u32>((u32)c->cu_count * (1024u / c->pb_gather_block), std::max(1u, c->pb_n_items));
+    {   // records of the persistent gather pass: everything an item needs in one place.  Items are dealt to the
+        // workgroups here, longest first, each to the workgroup with the least work so far (cost = bytes streamed + a
+        // fixed share for the fold), and laid out workgroup by workgroup.
+        const u32 G = c->pb_gather_grid;
         std::vector<u32> order(c->pb_n_items);
         for (u32 i = 0; i < c->pb_n_items; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
-            return items[4 * (size_t)a + 2] - items[4 * (size_t)a + 1] > items[4 * (size_t)b + 2] - items[4 * (size_t)b + 1];
-        });
-        std::vector<u32> rec((size_t)c->pb_n_items * 8, 0u);
-        for (u32 i = 0; i < c->pb_n_items; ++i) {
-            const u32 *it = &items[4 * (size_t)order[i]];
-            const u32 R = it[0];
-            u32 *o = &rec[8 * (size_t)i];
-            o[0] = it[1]; o[1] = it[2]; o[2] = row0[R]; o[3] = row0[R + 1] - row0[R]; o[4] = rep[R]; o[5] = it[3];
+        auto cost = [&](u32 i) {
+            const u32 R = items[4 * (size_t)i];
+            return 10ull * (items[4 * (size_t)i + 2] - items[4 * (size_t)i + 1]) + 16ull * (row0[R + 1] - row0[R]) + 24000ull;
+        };
+        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return cost(a) > cost(b); });
+        std::vector<std::vector<u32>> lists(G);
+        std::priority_queue<std::pair<u64, u32>, std::vector<std::pair<u64, u32>>, std::greater<std::pair<u64, u32>>> heap;
+        for (u32 w = 0; w < G; ++w) heap.push({0ull, w});
+        for (u32 i : order) {
+            auto [load, w] = heap.top();
+            heap.pop();
+            lists[w].push_back(i);
+            heap.push({load + cost(i), w});
         }
+        std::vector<u32> rec((size_t)c->pb_n_items * 8, 0u), begin((size_t)G + 1, 0u);
+        size_t k = 0;
+        for (u32 w = 0; w < G; ++w) {
+            begin[w] = (u32)k;
+            for (u32 i : lists[w]) {
+                const u32 *it = &items[4 * (size_t)i];
+                const u32 R = it[0];
+                u32 *o = &rec[8 * k++];
+                o[0] = it[1]; o[1] = it[2]; o[2] = row0[R]; o[3] = row0[R + 1] - row0[R]; o[4] = rep[R]; o[5] = it[3];
+            }
+        }
+        begin[G] = (u32)k;
         LZX_TRY(pb_alloc(&c->d_pb_items2, rec.size()));
+        LZX_TRY(pb_alloc(&c->d_pb_wg_begin, begin.size()));
         if (!rec.empty()) LZX_HIP(hipMemcpyAsync(c->d_pb_items2, rec.data(), sizeof(u32) * rec.size(), hipMemcpyHostToDevice, st));
+        LZX_HIP(hipMemcpyAsync(c->d_pb_wg_begin, begin.data(), sizeof(u32) * begin.size(), hipMemcpyHostToDevice, st));
+        if (c->pb_stamps_opt > 0) {   // debug library: per-workgroup time stamps of the persistent passes
+            LZX_TRY(pb_alloc(&c->d_pb_stamps, 3 * 4096));
+            LZX_HIP(hipMemsetAsync(c->d_pb_stamps, 0, sizeof(unsigned long long) * 3 * 4096, st));
+        }
         LZX_TRY(pb_alloc(&c->d_pb_queue, 4));
         LZX_HIP(hipMemsetAsync(c->d_pb_queue, 0, sizeof(u32) * 4, st));
         for (u32 &b : c->pb_qbase) b = 0;
@@ -1494,7 +1549,6 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     c->pb_nr = nr;
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     (void)waves_per_wg;
-    c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2, std::max(1u, c->pb_n_items));   // one item per workgroup at a time
     c->pb_finish_grid = (c->pb_n_multi + c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;   // + the split rows of k_spmv
     return LZX_OK;
 }
@@ -1522,9 +1576,14 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         return LZX_OK;
     }
     const size_t lds1 = ((size_t)c->pb_cb + 2 + 16 * 66) * sizeof(double);
+#ifdef LZX_DEBUG_KNOBS
     static const int ablate = getenv("LZX_ABLATE") ? atoi(getenv("LZX_ABLATE")) : 0;
     auto kern = c->pb_cb == 8192 ? (ablate ? k_pb_scatter<8192, true> : k_pb_scatter<8192, false>)
                                  : (ablate ? k_pb_scatter<LZX_PB_CB, true> : k_pb_scatter<LZX_PB_CB, false>);
+#else
+    const int ablate = 0;
+    auto kern = c->pb_cb == 8192 ? k_pb_scatter<8192, false> : k_pb_scatter<LZX_PB_CB, false>;
+#endif
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     const bool persistent = c->pb_persist_opt != 0 && !ablate;
@@ -1539,7 +1598,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
             const u32 grid = std::min<u32>(n, (u32)c->cu_count * (c->pb_cb == 8192 ? 2u : 1u));
             hipLaunchKernelGGL(kern2, dim3(grid), dim3(1024), lds1p, c->stream, c->d_pb_unit + 5 * (size_t)u0, n, c->d_pb_queue + q,
                                c->pb_qbase[q], c->d_pbr_code, c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol),
-                               c->d_pb_dst, x, c->xlen, c->d_pb_val);
+                               c->d_pb_dst, x, c->xlen, c->d_pb_val, c->d_pb_stamps ? c->d_pb_stamps + 4096 * q : nullptr);
             c->pb_qbase[q] += n + grid;
             return;
         }
@@ -1564,13 +1623,13 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     if (c->phase_mask_opt & 8) {
         // experiment: scatter pass alone
     } else if (persistent) {
-        const size_t lds2p = lds2 + 16;
-        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather2),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p));
-        hipLaunchKernelGGL(k_pb_gather2, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2p, c->stream,
-                           reinterpret_cast<const uint4 *>(c->d_pb_items2), c->pb_n_items, c->d_pb_queue + 2, c->pb_qbase[2],
-                           c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials);
-        c->pb_qbase[2] += c->pb_n_items + c->pb_gather_grid;
+        const u32 block = c->pb_gather_block;
+        const size_t lds2p = ((size_t)(block / 64) * (LZX_PB_RB + 8) + block / 64) * sizeof(double) + 16;
+        auto gk = block == 256 ? k_pb_gather2<256> : k_pb_gather2<512>;
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2p));
+        hipLaunchKernelGGL(gk, dim3(c->pb_gather_grid), dim3(block), lds2p, c->stream,
+                           reinterpret_cast<const uint4 *>(c->d_pb_items2), c->d_pb_wg_begin, c->d_pb_lrow, c->d_pb_val, v, q_loc,
+                           c->d_pb_part, partials, c->d_pb_stamps ? c->d_pb_stamps + 8192 : nullptr);
     } else
     hipLaunchKernelGGL(k_pb_gather, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_lrow,

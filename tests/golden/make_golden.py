@@ -43,6 +43,8 @@ def tie_last_to_first(csr):
 
 
 CASES = {
+    # BASELINE.json configs[0] (C1): serial/main.cc on a 10k-node Erdos-Renyi graph, k = 20 -- bench.py's workload c1
+    "er_c1_n10000": (lambda: O.gen_er(10000, 100000, 1234), 20),
     "er_n1000": (lambda: O.gen_er(1000, 5000, 1234), 20),
     "er_n4000_deg20": (lambda: O.gen_er(4000, 40000, 1234), 20),
     "rmat_n4096": (lambda: tie_last_to_first(O.gen_rmat(12, 4096, 30000, 1234)), 20),
@@ -56,7 +58,10 @@ def main():
     assert O.ref() is not None, "oracle/_ref could not be built (is /root/reference mounted?)"
     import scipy.sparse as sp
     import scipy.sparse.linalg as sla
+    only = set(sys.argv[1:])   # no arguments: regenerate everything
     for name, (make, k) in CASES.items():
+        if only and name not in only:
+            continue
         ro, ci = make()
         n = len(ro) - 1
         deg = np.diff(ro.astype(np.int64))

@@ -67,6 +67,43 @@ def test_cpp_classes_device_path(pkg, tmp_path):
             assert np.abs(ans - g["ans"]).max() <= 1e-10 * np.abs(g["ans"]).max()
 
 
+def test_cpp_classes_several_gpu_handles_and_device_ingest(pkg, tmp_path, monkeypatch):
+    """The class path the way parallel-two-cards drives its cards: adjMatrix::load (parallel parse, CSR built by the
+    device ingest and kept resident) -> lanczosDecomp(cuda) over 1 and over 3 handles (sharing this box's one GPU)
+    -> host multOut (basis downloaded on first use) and cu_multOut; a second decomposition re-uses the graph."""
+    pkg.lib()
+    _u32p = ctypes.POINTER(ctypes.c_uint32)
+    H = ctypes.CDLL(os.path.join(HOST_DIR, "libmschpc_host.so"))
+    H.host_last_error.restype = ctypes.c_char_p
+    H.host_load_path.argtypes = [ctypes.c_char_p, _u32p, _u32p, ctypes.c_uint, _u32p]
+    H.host_load_path.restype = ctypes.c_long
+    H.host_expm_path_devices.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                         _f64p, ctypes.c_uint, _f64p, _f64p, _u32p]
+    H.host_expm_path_devices.restype = ctypes.c_long
+    monkeypatch.setenv("LZX_NO_CSR_CACHE", "1")
+    for path in (GOLDEN[0], GOLDEN[-2]):          # the C1 graph and a skewed R-MAT one
+        g = np.load(path)
+        n, k = int(g["mtx_n"]), int(g["k"])
+        mtx = str(tmp_path / "g.mtx")
+        write_pairs(mtx, n, g["mtx_pairs"])
+        ro = np.zeros(n + 1, dtype=np.uint32)
+        ci = np.zeros(2 * len(g["mtx_pairs"]) + 1, dtype=np.uint32)
+        info = np.zeros(4, dtype=np.uint32)
+        edges = H.host_load_path(mtx.encode(), ro.ctypes.data_as(_u32p), ci.ctypes.data_as(_u32p), len(ci), info.ctypes.data_as(_u32p))
+        assert edges == int(g["ref_edge_count"]), H.host_last_error()
+        assert info[1] == 1, "the loader did not use the device ingest on a GPU box"
+        assert np.array_equal(ro, g["ref_row_offset"]) and np.array_equal(ci[:2 * edges], g["ref_col_idx"])   # bit-exact
+        for devices in ([0], [0, 0, 0]):
+            for device_multout in (0, 1):
+                ans, used = np.zeros(n), np.zeros(1, dtype=np.uint32)
+                dv = (ctypes.c_int * len(devices))(*devices)
+                rc = H.host_expm_path_devices(mtx.encode(), k, dv, len(devices), device_multout, ans.ctypes.data_as(_f64p), n,
+                                              None, None, used.ctypes.data_as(_u32p))
+                assert rc == n, H.host_last_error()
+                assert used[0] == len(devices)
+                assert np.abs(ans - g["ans"]).max() <= 1e-10 * np.abs(g["ans"]).max(), (devices, device_multout)
+
+
 def test_final_cli(tmp_path):
     g = np.load(GOLDEN[0])
     n = int(g["mtx_n"])

@@ -47,11 +47,72 @@ def test_c2_full_size(pkg, oracle):
     eng.close()
 
 
-def test_c3_full_size_properties(pkg):
+def test_c2_k50_against_oracle(pkg, oracle):
+    """BASELINE C2 at its own Krylov dimension, k = 50, against the oracle.  lambda_max of this graph is ~1e3, so e^A x
+    overflows fp64 (as the reference's own dense runs report NaN); the north-star criterion is checked on the
+    overflow-safe, converged functional of test_gpu_parity.shift_weights (e^(s (A - theta_max)) x, s theta_max = 40),
+    and every one of the 50 columns of the basis is pinned by the three-term recurrence against the ORACLE's SpMV."""
+    from test_gpu_parity import REL_INF_TOL, check_recurrence, rel_inf, shift_weights
+    O = oracle
+    eng = pkg.Engine(0)
+    eng.gen_rmat(20, 1 << 20, 20_000_000, 1234)
+    rp, ci = eng.get_graph_csr()
+    n, k = 1 << 20, 50
+    a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, np.ones(n), q_colmajor=True)
+    a, b, Q, xn, st = eng.lanczos(np.ones(n), k)
+    assert xn == xn_ref and st["iters"] == k
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    check_recurrence(O, rp, ci, a, b, Q, "c2_k50")
+    ref = shift_weights(O, a_ref, b_ref, xn_ref) @ Q_ref
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    assert rel_inf(shift_weights(O, a, b, xn) @ Q, ref) <= REL_INF_TOL
+    assert rel_inf(eng.multout(shift_weights(O, a, b, xn)), ref) <= REL_INF_TOL
+    eng.close()
+
+
+def test_eight_ranks_in_process_c2(pkg, oracle):
+    """The 8-rank layout of C4 (rows dealt by degree rank, only the vertices that have an edge exchanged, the
+    two-chunk exchange that overlaps the blocked SpMV and the single all-gather) on 8 in-process handles sharing this
+    box's one GPU, on the C2 graph, against the oracle: SpMV 1e-13, first coefficients, recurrence of every column,
+    shifted centrality vector 1e-10.  The transport here is device-to-device copies; under torch.distributed.run the
+    same two operations are RCCL calls (csrc/lzx_comm.hip)."""
+    from test_gpu_parity import REL_INF_TOL, check_leading_coefficients, check_recurrence, rel_inf, shift_weights
+    O = oracle
+    n, k = 1 << 20, 6
+    rp, ci = O.gen_rmat(20, n, 20_000_000, 1234)
+    a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, np.ones(n), q_colmajor=True)
+    ref = shift_weights(O, a_ref, b_ref, xn_ref) @ Q_ref
+    x = np.random.default_rng(8).random(n)
+    y_ref = O.spmv(rp, ci, x)
+    for overlap in (1, 0):
+        grp = pkg.LocalGroup([0] * 8, overlap_exchange=overlap)
+        grp.set_graph_csr(rp, ci)
+        gi = grp.engines[5].info()
+        assert gi["world"] == 8 and gi["rank"] == 5 and gi["pb_entries"] > 0
+        assert (gi["exchange_chunk0"] > 0) == (overlap == 1)
+        assert 0 < gi["exchange_slice"] <= -(-gi["active_vertices"] // 8 // 64) * 64 + 64
+        assert abs(gi["nnz_local"] * 8 - gi["nnz"]) <= 0.02 * gi["nnz"]          # rows dealt by degree rank: balanced
+        assert np.allclose(grp.spmv(x), y_ref, rtol=1e-13, atol=0)
+        a, b, Q, xn, st = grp.lanczos(np.ones(n), k)
+        assert xn == xn_ref
+        check_leading_coefficients(a, b, a_ref, b_ref, ("local8", overlap))
+        check_recurrence(O, rp, ci, a, b, Q, ("local8", overlap))
+        assert rel_inf(grp.multout(shift_weights(O, a, b, xn)), ref) <= REL_INF_TOL
+        grp.close()
+
+
+def test_c3_full_size_properties(pkg, oracle):
+    O = oracle
     eng = pkg.Engine(0)
     eng.gen_rmat(24, 10_000_000, 200_000_000, 1234)       # BASELINE C3 / C4 graph
     gi = eng.info()
     assert gi["n"] == 10_000_000 and 380_000_000 < gi["nnz"] < 400_000_000
+    # one SpMV of a non-constant vector against the ORACLE (the row-sum check below is exact but blind to which x
+    # entry a column reads): all 360 column bands of the blocked path, split rows included
+    rp, ci = eng.get_graph_csr()
+    x = np.random.default_rng(33).random(gi["n"])
+    assert np.allclose(eng.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+    del rp, ci
     check_properties(eng, gi["n"], 5, np.random.default_rng(3))
     eng.close()
 

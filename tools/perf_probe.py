@@ -37,6 +37,12 @@ if __name__ == "__main__":
     sets = [a[1:] for a in sys.argv[1:] if a.startswith("@")]
     opts = [dict(), dict(hub_entries=0), dict(hub_entries=16384, wgs_per_cu=1), dict(hub_entries=4096),
             dict(nt_index_loads=1), dict(hub_entries=0, nt_index_loads=1), dict(wgs_per_cu=1), dict(hub_entries=0, wgs_per_cu=4)]
+    if "diag" in sets:
+        opts = [dict(pb_stamps=1), dict(pb_stamps=1, pb_target=8192), dict(pb_stamps=1, pb_target=131072), dict(pb_stamps=1, pb_run_align=4),
+                dict(pb_stamps=1, phase_mask=3 + 8), dict(pb_stamps=1, phase_mask=3 + 4), dict(pb_stamps=1, pb_unit=32768), dict(pb_stamps=1, pb_unit=262144)]
+    if "diag2" in sets:
+        opts = [dict(pb_stamps=1), dict(pb_stamps=1, pb_gather_waves=4), dict(pb_stamps=1, hub_entries=2), dict(pb_stamps=1, hub_entries=1024),
+                dict(pb_stamps=1, hub_entries=4096), dict(pb_stamps=1, hub_entries=8192), dict(pb_stamps=1, hub_entries=2, pb_gather_waves=4)]
     if "persist" in sets:
         opts = [dict(), dict(pb_persistent=0), dict(), dict(pb_persistent=0)]
     if "plain" in sets:
