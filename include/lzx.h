@@ -76,6 +76,10 @@ typedef struct lzx_graph_info {
     uint64_t pb_reduced_entries; /* of pb_entries: entries of the reduced bands, which travel as partial row sums */
     uint64_t exchange_chunk0;    /* doubles per rank in the first of the two all-gathers that overlap the blocked SpMV
                                     (0 = one all-gather per iteration) */
+    uint64_t exchange_recv;      /* doubles this rank receives from the OTHER ranks per iteration: (world - 1) *
+                                    exchange_slice with the plain all-gather; with the two-chunk exchange chunk 1 is
+                                    sparse -- each peer sends only the entries this rank's rows reference -- and this
+                                    is (world - 1) * exchange_chunk0 + what the peers pack for this rank */
 } lzx_graph_info;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -188,6 +192,8 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           rows are summed in the reference's order and come out bit-identical to serial/
  *   "overlap_exchange"      several ranks: 1 / 0 allow / forbid the two-chunk all-gather that overlaps the blocked
  *                           SpMV (default: allowed)
+ *   "sparse_exchange"       1 / 0: with the two-chunk exchange, send each peer only the entries of the second chunk its rows
+ *                           reference (default 1)
  *   "lazy_normalisation"    1: multiply (and, with several ranks, exchange) the unnormalised vector, so that alpha and
  *                           beta come out of one reduction per iteration (one 2-double all-reduce) and one vector kernel;
  *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on

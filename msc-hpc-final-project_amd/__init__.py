@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "liblzx.so")
 # the same code built with -DLZX_DEBUG_KNOBS: experiment knobs, test hooks, ablation switches (Makefile, `make debug`)
 DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
 # what the product library's lzx_set_option knows (include/lzx.h); any other option name selects the debug library
-PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "lazy_normalisation", "timing_marks_every")
+PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "lazy_normalisation",
+                   "timing_marks_every")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -43,7 +44,7 @@ class LzxGraphInfo(ctypes.Structure):
                 ("pb_entries", ctypes.c_uint64), ("active_vertices", ctypes.c_uint64),
                 ("exchange_slice", ctypes.c_uint64), ("hub_entries", ctypes.c_uint32), ("world", ctypes.c_uint32), ("rank", ctypes.c_uint32),
                 ("reserved_", ctypes.c_uint32), ("pb_values", ctypes.c_uint64), ("pb_reduced_entries", ctypes.c_uint64),
-                ("exchange_chunk0", ctypes.c_uint64)]
+                ("exchange_chunk0", ctypes.c_uint64), ("exchange_recv", ctypes.c_uint64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -99,6 +99,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
     else if (!strcmp(name, "overlap_exchange")) c->overlap_opt = value;
     else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
+    else if (!strcmp(name, "sparse_exchange")) c->sparse_opt = value;
     else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
 #ifdef LZX_DEBUG_KNOBS
     // experiment knobs and test hooks: only in liblzx_dbg.so (make debug), which tests/ and tools/perf_probe.py load
@@ -115,6 +116,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "pb_persistent")) c->pb_persist_opt = value;
     else if (!strcmp(name, "pb_stamps")) c->pb_stamps_opt = value;
+    else if (!strcmp(name, "pb_order")) c->pb_order_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
@@ -364,11 +366,16 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
                 LZX_HIP(hipSetDevice(c->device));
                 LZX_HIP(hipEventRecord(c->ev_c0, c->stream2));
             }
-            for (size_t i = 0; i < cs.size(); ++i) {
-                src[i] = cs[i]->d_u[(j + 1) & 1] + cs[i]->xs0;
-                dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
+            if (c0->sparse) {   // every peer gets only what its rows reference
+                for (size_t i = 0; i < cs.size(); ++i) src[i] = cs[i]->d_u[(j + 1) & 1];
+                LZX_TRY(lzx_comm_sparse_chunk1(cs, src.data()));
+            } else {
+                for (size_t i = 0; i < cs.size(); ++i) {
+                    src[i] = cs[i]->d_u[(j + 1) & 1] + cs[i]->xs0;
+                    dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
+                }
+                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
             }
-            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
                 LZX_HIP(hipEventRecord(c->ev_c1, c->stream2));
@@ -465,11 +472,16 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
                 LZX_HIP(hipSetDevice(c->device));
                 LZX_HIP(hipEventRecord(c->ev_c0, c->stream2));
             }
-            for (size_t i = 0; i < cs.size(); ++i) {
-                src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq + cs[i]->xs0;
-                dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
+            if (c0->sparse) {
+                for (size_t i = 0; i < cs.size(); ++i) src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
+                LZX_TRY(lzx_comm_sparse_chunk1(cs, src.data()));
+            } else {
+                for (size_t i = 0; i < cs.size(); ++i) {
+                    src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq + cs[i]->xs0;
+                    dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
+                }
+                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
             }
-            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
                 LZX_HIP(hipEventRecord(c->ev_c1, c->stream2));
@@ -792,11 +804,17 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
         LZX_TRY(rc);
         LZX_HIP(hipStreamSynchronize(c->stream));
         float t[4] = {0, 0, 0, 0};
+        const bool scatter_first = c->pb && c->pb_order_opt != 0 && !(c->side_opt > 0);
         (void)hipEventElapsedTime(&t[0], c->trace_ev[0], c->trace_ev[1]);
-        (void)hipEventElapsedTime(&t[1], c->trace_ev[1], c->trace_ev[2]);
-        if (c->pb) {
+        if (scatter_first) {
             (void)hipEventElapsedTime(&t[2], c->trace_ev[2], c->trace_ev[3]);
-            (void)hipEventElapsedTime(&t[3], c->trace_ev[3], c->trace_ev[4]);
+            (void)hipEventElapsedTime(&t[3], c->trace_ev[5], c->trace_ev[4]);
+        } else {
+            (void)hipEventElapsedTime(&t[1], c->trace_ev[1], c->trace_ev[2]);
+            if (c->pb) {
+                (void)hipEventElapsedTime(&t[2], c->trace_ev[2], c->trace_ev[3]);
+                (void)hipEventElapsedTime(&t[3], c->trace_ev[3], c->trace_ev[4]);
+            }
         }
         fprintf(stderr, "[lzx trace] k_spmv %.4f ms  long_finish %.4f ms  pb_scatter %.4f ms  pb_gather(+finish) %.4f ms\n",
                 t[0], t[1], t[2], t[3]);
@@ -808,7 +826,7 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
             for (int q = 0; q < 3; ++q) {
                 std::vector<double> st, en, busy;
                 unsigned long long t0 = ~0ull;
-                u64 units = 0, restaged = 0;
+                u64 units = 0, restaged = 0, tred = 0, tplain = 0;
                 for (int w = 0; w < 1024; ++w) {
                     const unsigned long long *r = &h[(size_t)q * 4096 + 4 * w];
                     if (r[1] == 0) continue;
@@ -820,8 +838,10 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
                     st.push_back((r[0] - t0) * 0.01);
                     en.push_back((r[1] - t0) * 0.01);
                     busy.push_back((r[1] - r[0]) * 0.01);
-                    units += r[2];
-                    restaged += r[3];
+                    units += r[2] & 0xffffffffull;
+                    restaged += q < 2 ? r[2] >> 32 : 0;
+                    tred += r[3] & 0xffffffffull;
+                    tplain += r[3] >> 32;
                 }
                 if (en.empty()) continue;
                 std::sort(st.begin(), st.end());
@@ -831,6 +851,8 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
                 fprintf(stderr, "[lzx stamps] %s: %zu workgroups, %llu units, %llu restagings | start us: max %.1f | end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | busy us: min %.1f p50 %.1f max %.1f\n",
                         nm[q], en.size(), (unsigned long long)units, (unsigned long long)restaged, st.back(), en.front(), pct(en, 0.1),
                         pct(en, 0.5), pct(en, 0.9), en.back(), busy.front(), pct(busy, 0.5), busy.back());
+                if (q < 2) fprintf(stderr, "[lzx stamps]   wavefront 0, mean over workgroups: reduced steps %.1f us, plain quads %.1f us\n",
+                                   tred * 0.01 / en.size(), tplain * 0.01 / en.size());
             }
         }
     }

@@ -22,6 +22,10 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -46,6 +50,10 @@ int rccl_load()
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllReduce, "ncclAllReduce");
     SYM(AllGather, "ncclAllGather");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.lib = lib;
@@ -217,5 +225,58 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
         }
     }
     LZX_TRY(cross_barrier(cs, on_stream2));
+    return LZX_OK;
+}
+
+// Chunk 1 of the per-iteration exchange in its sparse form (lzx_graph.hip, k_sx_mark): rank i receives from rank r
+// only the entries of r's slice that i's rows reference, packed, into its own segment for r behind chunk 0.  Every
+// rank packs once for all peers (one gather kernel), then one grouped send/receive per peer (RCCL: ncclSend / ncclRecv
+// inside one group, xGMI point to point -- no ring, no rank forwards what another one needs) or, inside one process,
+// one device-to-device copy per pair.  On the exchange streams.
+int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc)
+{
+    lzx_ctx *c0 = cs[0];
+    const int world = c0->world;
+    if (!c0->sparse) LZX_FAIL(LZX_ERR_STATE, "sparse exchange was not prepared");
+    if (c0->comm_kind == 2) {
+        lzx_ctx *c = c0;
+        const int me = c->rank;
+        ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_comm);
+        LZX_TRY(lzx_launch_sx_pack(c, slice_loc[0], c->stream2));
+        double *seg = c->d_xbuf + (size_t)world * c->xs0;
+        const u32 own = c->sx_send_off[me + 1] - c->sx_send_off[me];
+        if (own)
+            LZX_HIP(hipMemcpyAsync(seg + c->sx_recv_off[me], c->d_sx_sendbuf + c->sx_send_off[me], sizeof(double) * own,
+                                   hipMemcpyDeviceToDevice, c->stream2));
+        LZX_NCCL(g_rccl.GroupStart());
+        for (int p = 0; p < world; ++p) {
+            if (p == me) continue;
+            const u32 ns = c->sx_send_off[p + 1] - c->sx_send_off[p], nr = c->sx_recv_off[p + 1] - c->sx_recv_off[p];
+            if (ns) LZX_NCCL(g_rccl.Send(c->d_sx_sendbuf + c->sx_send_off[p], ns, ncclDouble, p, comm, c->stream2));
+            if (nr) LZX_NCCL(g_rccl.Recv(seg + c->sx_recv_off[p], nr, ncclDouble, p, comm, c->stream2));
+        }
+        LZX_NCCL(g_rccl.GroupEnd());
+        return LZX_OK;
+    }
+    if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
+    for (int i = 0; i < world; ++i) {
+        LZX_HIP(hipSetDevice(cs[i]->device));
+        LZX_TRY(lzx_launch_sx_pack(cs[i], slice_loc[i], cs[i]->stream2));
+    }
+    LZX_TRY(cross_barrier(cs, true));
+    for (int i = 0; i < world; ++i) {
+        lzx_ctx *c = cs[i];
+        LZX_HIP(hipSetDevice(c->device));
+        double *seg = c->d_xbuf + (size_t)world * c->xs0;
+        for (int r = 0; r < world; ++r) {
+            const u32 nr = c->sx_recv_off[r + 1] - c->sx_recv_off[r];
+            const u32 ns = cs[r]->sx_send_off[i + 1] - cs[r]->sx_send_off[i];
+            if (nr != ns) LZX_FAIL(LZX_ERR_STATE, "sparse exchange: rank %d expects %u entries of rank %d, which packs %u", i, nr, r, ns);
+            if (nr)
+                LZX_HIP(hipMemcpyAsync(seg + c->sx_recv_off[r], cs[r]->d_sx_sendbuf + cs[r]->sx_send_off[i], sizeof(double) * nr,
+                                       hipMemcpyDefault, c->stream2));
+        }
+    }
+    LZX_TRY(cross_barrier(cs, true));
     return LZX_OK;
 }

@@ -41,6 +41,13 @@ int lzx_graph_release(lzx_ctx *c)
     dev_free(c->d_row_ptr);
     dev_free(c->d_col_idx);
     dev_free(c->d_gidx_of_old);
+    dev_free(c->d_sx_send_idx);
+    dev_free(c->d_sx_sendbuf);
+    dev_free(c->d_sx_map);
+    c->sparse = false;
+    c->xc1 = 0;
+    c->sx_recv_off.clear();
+    c->sx_send_off.clear();
     dev_free(c->d_slice_off);
     dev_free(c->d_slice_w);
     dev_free(c->d_sell_cols);
@@ -90,6 +97,64 @@ __global__ void k_rank_maps(const u32 *sorted_ids, u32 *gidx_of_old, u32 *code_o
     // exchange layout (meaningful for degree > 0): chunk 0 = [world][xs0], chunk 1 = [world][xs - xs0]
     const u32 x = l < xs0 ? p * xs0 + l : world * xs0 + p * (xs - xs0) + (l - xs0);
     code_of_old[o] = (r < hub) ? (u32)r : hub + x;
+}
+
+// ---- sparse exchange of chunk 1 -------------------------------------------------------------------------------
+// Every rank holds the whole graph, so each one derives BOTH sides from it without talking to anybody: which chunk-1
+// entries of every peer its own rows reference (ref: its receive layout), and which of its own chunk-1 entries every
+// peer's rows reference (want: its send lists).  One wavefront per row of the WHOLE graph, rows strided over the grid.
+//   ref [r * L1 + l] = 1: a row of rank `me` has an entry in the column that is local entry xs0 + l of rank r
+//   want[p * L1 + l] = 1: a row of rank p has an entry in the column that is local entry xs0 + l of rank `me`
+__global__ void __launch_bounds__(64)
+k_sx_mark(const u64 *row_ptr, const u32 *col_idx, const u32 *sorted_ids, const u32 *code_of_old, u64 n_active, u32 world, u32 me,
+          u32 hub, u32 xs0, u32 L1, uint8_t *ref, uint8_t *want)
+{
+    const u32 lane = threadIdx.x;
+    const u32 c1 = hub + world * xs0;   // first chunk-1 code
+    for (u64 r = blockIdx.x; r < n_active; r += gridDim.x) {
+        const u32 p = (u32)(r % world);
+        const u32 o = sorted_ids[r];
+        const u64 beg = row_ptr[o], end = row_ptr[o + 1];
+        for (u64 k = beg + lane; k < end; k += 64) {
+            const u32 code = code_of_old[col_idx[k]];
+            if (code < c1) continue;
+            const u32 x = code - c1, owner = x / L1, l = x % L1;
+            if (p == me) ref[x] = 1;
+            if (owner == me) want[(size_t)p * L1 + l] = 1;
+        }
+    }
+}
+
+__global__ void k_widen_u8(const uint8_t *in, u64 count, u32 *out)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = in[i];
+}
+
+// packed positions: codes of referenced chunk-1 columns move to c1 + newpos; map[newpos] = hand-over position
+__global__ void k_sx_remap(const u32 *sorted_ids, u32 *code_of_old, u64 n_active, u32 world, u32 hub, u32 xs0, u32 L1, u32 n_loc_pad,
+                           const uint8_t *ref, const u32 *newpos, u32 *map)
+{
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_active) return;
+    const u32 o = sorted_ids[r];
+    const u32 c1 = hub + world * xs0;
+    const u32 code = code_of_old[o];
+    if (code < c1) return;
+    const u32 x = code - c1;
+    if (ref[x]) {
+        code_of_old[o] = c1 + newpos[x];
+        map[newpos[x]] = (x / L1) * n_loc_pad + xs0 + (x % L1);
+    } else {
+        code_of_old[o] = c1;   // never referenced by this rank's rows
+    }
+}
+
+// send list: entry (p, l) with want set -> idx[sendpos] = xs0 + l
+__global__ void k_sx_lists(const uint8_t *want, const u32 *sendpos, u64 count, u32 L1, u32 xs0, u32 *idx)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && want[i]) idx[sendpos[i]] = xs0 + (u32)(i % L1);
 }
 
 __global__ void k_count_active(const u32 *sorted_deg, u64 n, unsigned long long *count)
@@ -351,6 +416,61 @@ int lzx_graph_prepare(lzx_ctx *c)
     const u32 sentinel = pb ? c->hub_real : c->hub + (u32)((u64)world * c->xs);
     hipLaunchKernelGGL(k_rank_maps, dim3(gb), dim3(256), 0, st, d_sids, c->d_gidx_of_old, d_code, n,
                        world, c->n_loc_pad, c->xs, c->xs0, c->hub_real);
+
+    // ---- 1b. sparse exchange of chunk 1: this rank's packed x layout and its send lists (see k_sx_mark) ----
+    c->sparse = false;
+    if (c->overlap && world > 1 && c->sparse_opt != 0 && c->xs > c->xs0) {
+        const u32 L1 = c->xs - c->xs0;
+        const u64 cnt = (u64)world * L1;
+        uint8_t *d_ref = nullptr, *d_want = nullptr;
+        u32 *d_w32 = nullptr, *d_pos = nullptr, *d_spos = nullptr;
+        auto sx_free = [&]() { dev_free(d_ref); dev_free(d_want); dev_free(d_w32); dev_free(d_pos); dev_free(d_spos); };
+#define SX(call) do { rc = (call); if (rc != LZX_OK) { sx_free(); cleanup(); return rc; } } while (0)
+#define SX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); sx_free(); cleanup(); \
+        return e_ == hipErrorOutOfMemory ? LZX_ERR_NOMEM : LZX_ERR_HIP; } } while (0)
+        SX(dev_alloc(&d_ref, cnt)); SX(dev_alloc(&d_want, cnt));
+        SX(dev_alloc(&d_w32, cnt + 1)); SX(dev_alloc(&d_pos, cnt + 1)); SX(dev_alloc(&d_spos, cnt + 1));
+        SX_HIP(hipMemsetAsync(d_ref, 0, cnt, st));
+        SX_HIP(hipMemsetAsync(d_want, 0, cnt, st));
+        hipLaunchKernelGGL(k_sx_mark, dim3((u32)std::min<u64>(std::max<u64>(c->n_active, 1), 1u << 20)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx,
+                           d_sids, d_code, c->n_active, world, rank, c->hub_real, c->xs0, L1, d_ref, d_want);
+        auto scan = [&](const uint8_t *flags, u32 *out) -> int {
+            hipLaunchKernelGGL(k_widen_u8, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, st, flags, cnt, d_w32);
+            LZX_HIP(hipMemsetAsync(d_w32 + cnt, 0, sizeof(u32), st));
+            size_t sb = 0;
+            LZX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, d_w32, out, cnt + 1, st));
+            void *tmp = nullptr;
+            LZX_HIP(hipMalloc(&tmp, sb ? sb : 16));
+            hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, sb, d_w32, out, cnt + 1, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            (void)hipFree(tmp);
+            LZX_HIP(e);
+            return LZX_OK;
+        };
+        SX(scan(d_ref, d_pos));
+        SX(scan(d_want, d_spos));
+        c->sx_recv_off.assign(world + 1, 0);
+        c->sx_send_off.assign(world + 1, 0);
+        for (u32 p = 0; p <= world; ++p) {
+            SX_HIP(hipMemcpyAsync(&c->sx_recv_off[p], d_pos + (u64)p * L1, sizeof(u32), hipMemcpyDeviceToHost, st));
+            SX_HIP(hipMemcpyAsync(&c->sx_send_off[p], d_spos + (u64)p * L1, sizeof(u32), hipMemcpyDeviceToHost, st));
+        }
+        SX_HIP(hipStreamSynchronize(st));
+        c->xc1 = c->sx_recv_off[world];
+        SX(dev_alloc(&c->d_sx_map, std::max<u64>(c->xc1, 1)));
+        SX(dev_alloc(&c->d_sx_send_idx, std::max<u32>(c->sx_send_off[world], 1)));
+        SX(dev_alloc(&c->d_sx_sendbuf, std::max<u32>(c->sx_send_off[world], 1)));
+        hipLaunchKernelGGL(k_sx_remap, dim3((u32)((c->n_active + 255) / 256)), dim3(256), 0, st, d_sids, d_code, c->n_active, world,
+                           c->hub_real, c->xs0, L1, c->n_loc_pad, d_ref, d_pos, c->d_sx_map);
+        hipLaunchKernelGGL(k_sx_lists, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, st, d_want, d_spos, cnt, L1, c->xs0, c->d_sx_send_idx);
+        SX_HIP(hipStreamSynchronize(st));
+        sx_free();
+#undef SX
+#undef SX_HIP
+        c->sparse = true;
+        c->xlen = (u64)world * c->xs0 + round_up((u32)c->xc1, LZX_SLICE) + LZX_TAIL;
+    }
 
     // ---- 2. this rank's rows ----
     PREP(dev_alloc(&d_old_of_local, c->n_loc_real)); PREP(dev_alloc(&d_deg_local, c->n_loc_real));
@@ -771,6 +891,12 @@ extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
     o->pb_reduced_entries = c->pb ? c->pbr_entries : 0;
     o->reserved_ = 0;
     o->exchange_chunk0 = c->overlap ? c->xs0 : 0;
+    o->exchange_recv = 0;
+    if (c->world > 1) {
+        o->exchange_recv = (u64)(c->world - 1) * c->xs;
+        if (c->sparse)
+            o->exchange_recv = (u64)(c->world - 1) * c->xs0 + c->xc1 - (c->sx_recv_off[c->rank + 1] - c->sx_recv_off[c->rank]);
+    }
     o->active_vertices = c->n_active;
     o->exchange_slice = c->world > 1 ? c->xs : 0;
     o->world = (uint32_t)c->world;

@@ -101,6 +101,16 @@ struct lzx_ctx {
                                        // high-degree end: nearly all gathers land there) and the remaining xs - xs0;
                                        // layout [world][xs0] then [world][xs - xs0] so each chunk is one all-gather and
                                        // the second one can travel while the SpMV already works on the first
+    // Sparse exchange of chunk 1 (overlapped mode): a rank receives from each peer only the entries its own rows
+    // reference, packed; its x layout is [world][xs0] (chunk 0, dense) followed by one packed segment per peer.
+    int64_t sparse_opt = -1;           // -1 auto (on with the two-chunk exchange), 0 off
+    bool sparse = false;
+    u64 xc1 = 0;                       // packed length of chunk 1 on this rank (all peers' segments)
+    std::vector<u32> sx_recv_off;      // [world + 1] offsets of the peers' segments inside the packed chunk 1
+    std::vector<u32> sx_send_off;      // [world + 1] offsets of what goes to each peer inside d_sx_sendbuf
+    u32 *d_sx_send_idx = nullptr;      // [sx_send_off[world]] local row index (>= xs0) of every packed entry, peer-major
+    double *d_sx_sendbuf = nullptr;    // [sx_send_off[world]]
+    u32 *d_sx_map = nullptr;           // [xc1] packed chunk-1 position -> position in the hand-over layout (p * n_loc_pad + l)
     u64 n_active = 0;                  // vertices of degree > 0
     u32 rows_live = 0;                 // this rank's rows that have an edge (a prefix of its rows), rounded up to whole slices
     u64 xlen = 0;                      // world * xs + LZX_TAIL: length of the vector the SpMV gathers from
@@ -167,11 +177,16 @@ struct lzx_ctx {
     uint8_t *d_pb_long_multi = nullptr; // [n_long64] 1: the split row is also listed in d_pb_multi
     u32 *d_pb_items2 = nullptr;        // [pb_n_items][8] the persistent gather pass's records, workgroup by workgroup:
                                        // begin, end, first row, rows, slots per row, total slot or ~0, 0, 0
+    u32 *d_pb_seg = nullptr;           // [segments][5] static scatter schedule: band, first / last step, first / last quad
+    u32 *d_pb_seg_begin = nullptr;     // first segment of every scatter workgroup, schedule 0 then schedule 1 (each + 1 end entry)
+    u32 pb_seg_groups[2] = {0, 0};     // workgroups of the two schedules (bands of chunk 0 / the rest)
+    u32 pb_seg_first[2] = {0, 0};      // where each schedule starts in d_pb_seg_begin
     u32 *d_pb_wg_begin = nullptr;      // [pb_gather_grid + 1] first record of each gather workgroup's fixed list
     u32 *d_pb_queue = nullptr;         // [4] ticket counters of the persistent scatter pass: chunk 0, chunk 1
     u32 pb_qbase[4] = {0, 0, 0, 0};    // value each counter will have when its next launch starts
     unsigned long long *d_pb_stamps = nullptr;   // [3][4096] debug library, option pb_stamps: per-workgroup start / end ticks
     int64_t pb_stamps_opt = -1;
+    int64_t pb_order_opt = -1;         // kernel order of the blocked SpMV (debug knob): -1/1 scatter, staged columns, gather; 0 staged columns first
     int64_t pb_gwaves_opt = -1;        // wavefronts per gather workgroup (debug knob): 8 (default) or 4
     u32 pb_gather_block = 512;
     int64_t pb_persist_opt = -1;       // persistent passes: -1/1 on, 0 = one workgroup per unit / static item lists
@@ -219,8 +234,9 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
                    const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total);
 void lzx_pb_release(lzx_ctx *c);
 // chunk1_ready (may be null): event after which the second chunk of the exchange layout is valid in x
+// phases: 1 = scatter pass, 2 = gather (+ finish) pass, 3 = both
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
-                  hipEvent_t v_ready);
+                  hipEvent_t v_ready, int phases = 3);
 u32 lzx_pb_partials(const lzx_ctx *c);
 
 // ---- lzx_kernels.hip ----
@@ -260,6 +276,10 @@ inline bool lzx_exchanges(const lzx_ctx *c) { return c->world > 1 || (c->force_m
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count = 1);   // d_scal[slot .. slot+count) on every handle
 int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t count,
                        bool on_stream2 = false);
+// chunk 1 of the exchange, sparse form: every handle packs what each peer's rows reference out of slice_loc[i] (its
+// own slice of the new vector) and the packed pieces land in the peers' d_xbuf behind chunk 0; on the exchange streams
+int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
+int lzx_launch_sx_pack(lzx_ctx *c, const double *slice_loc, hipStream_t st);
 // everything queued so far on every handle's `from` stream happens before what is queued next on every `to` stream
 int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream2);
 void lzx_comm_release(lzx_ctx *c);

@@ -235,19 +235,22 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
             const u32 di = w0 + (base + (lane < cnt ? lane : 0)) * waves;
             const u64 d_off = a.slice_off[di];
             const u32 d_st = a.slice_w[di] >> 2;   // packets per lane
-            auto issue = [&](u32 j, uint4 (&f)[4], double &qrow) {
+            // PF packets of the next slice are in flight while this one is summed: 4 in plain mode; 8 in blocked mode,
+            // whose staged-only slices are 6.5 packets wide on average (C3) and whose kernel is bound by memory round trips
+            constexpr int PF = HUB == 2 ? 8 : 4;
+            auto issue = [&](u32 j, uint4 (&f)[PF], double &qrow) {
                 const PK *p = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, j)) + lane;
                 const u32 st = lane_u32(d_st, j);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) f[u] = load_idx4<NT>(p + (size_t)((u32)u < st ? u : 0) * 64);
+                for (int u = 0; u < PF; ++u) f[u] = load_idx4<NT>(p + (size_t)((u32)u < st ? u : 0) * 64);
                 qrow = a.q_loc[a.row0 + (w0 + (base + j) * waves) * 64 + lane];
             };
-            auto consume = [&](u32 j, const uint4 (&f)[4], double qrow) {
+            auto consume = [&](u32 j, const uint4 (&f)[PF], double qrow) {
                 const PK *p = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, j)) + lane;
                 const u32 st = lane_u32(d_st, j);
                 double acc = 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < PF; ++u) {
                     if ((u32)u < st) {
                         const double x0 = gather<HUB>(f[u].x, a.x, hubv, a.hub);
                         const double x1 = gather<HUB>(f[u].y, a.x, hubv, a.hub);
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
                         acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
                     }
                 }
-                u32 i = 4;
+                u32 i = PF;
                 for (; i + 4 <= st; i += 4) {
                     uint4 c[4];
 #pragma unroll
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
                 a.v[a.row0 + (w0 + (base + j) * waves) * 64 + lane] = acc;
                 dot += acc * qrow;
             };
-            uint4 fa[4], fb[4];
+            uint4 fa[PF], fb[PF];
             double qa, qb;
             issue(0, fa, qa);
             for (u32 j = 0; j < cnt; j += 2) {
@@ -485,6 +488,22 @@ __global__ void k_relayout(const double *io_layout, double *x, u32 world, u32 n_
     x[i] = io_layout[(size_t)p * n_loc_pad + l];
 }
 
+// the same with chunk 1 in its sparse form: [world][xs0] then this rank's packed segments (map = hand-over position)
+__global__ void k_relayout_sparse(const double *io_layout, double *x, u32 world, u32 n_loc_pad, u32 xs0, const u32 *map, u64 xc1)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 c0 = (u64)world * xs0;
+    if (i < c0) x[i] = io_layout[(size_t)(i / xs0) * n_loc_pad + (u32)(i % xs0)];
+    else if (i - c0 < xc1) x[i] = io_layout[map[i - c0]];
+}
+
+// sendbuf[i] = slice[idx[i]]: what every peer's rows reference of this rank's slice, peer by peer
+__global__ void k_sx_pack(const double *slice, const u32 *idx, u32 count, double *out)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = slice[idx[i]];
+}
+
 __global__ void k_permute_out(const double *full, const u32 *gidx, double *io, u64 n)
 {
     const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -554,11 +573,23 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     // which adds into the v it wrote, waits for it.  Measured: C3 +1..2 %, C2 -4 % (two more event operations per
     // SpMV) -- off by default.
     const bool side = c->pb && c->side_opt > 0 && !c->trace;
+    // Blocked mode: the scatter pass goes FIRST, the staged-columns kernel between it and the gather pass.  The gather
+    // pass reads the 0.6 GB of values the scatter pass has just written; straight behind it, it competes with the
+    // write-back of the quarter of them still dirty in the Infinity Cache (gather alone 0.21 ms, behind the scatter
+    // 0.25 ms on C3).  The staged-columns kernel in between is bound by round trips, not by bandwidth: the write-back
+    // drains in its shadow.  Both only read x, and the gather pass adds into the v that kernel wrote.
+    // (not with the two-chunk exchange: there the staged-columns kernel runs first, while chunk 1 is still on the wire)
+    const bool scatter_first = c->pb && !side && c->pb_order_opt != 0 && !l.chunk1_ready;
+    double *pb_partials = l.partials + c->spmv_grid + (c->pb ? 0 : c->fin_grid);
     hipStream_t hs = c->stream;
     if (side) {
         LZX_HIP(hipEventRecord(c->ev_fork, c->stream));
         LZX_HIP(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
         hs = c->stream3;
+    }
+    if (scatter_first) {
+        if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[2], c->stream));
+        LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, pb_partials, l.chunk1_ready, nullptr, 1));
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[0], c->stream));
     if (c->codes16) {
@@ -578,10 +609,15 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
                            l.partials + c->spmv_grid);
     }
     LZX_HIP(hipGetLastError());
-    if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[2], c->stream));
+    if (c->trace && !scatter_first) LZX_HIP(hipEventRecord(c->trace_ev[2], c->stream));
     // entries whose column is not staged in LDS: two streaming passes that add into v (lzx_pb.hip)
     if (side) LZX_HIP(hipEventRecord(c->ev_join, c->stream3));
-    LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, l.partials + c->spmv_grid + (c->pb ? 0 : c->fin_grid), l.chunk1_ready, side ? c->ev_join : nullptr));
+    if (scatter_first) {
+        if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[5], c->stream));
+        LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, pb_partials, nullptr, nullptr, 2));
+    } else {
+        LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, pb_partials, l.chunk1_ready, side ? c->ev_join : nullptr, 3));
+    }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[4], c->stream));
     return LZX_OK;
 }
@@ -662,8 +698,24 @@ int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io)
     return LZX_OK;
 }
 
+int lzx_launch_sx_pack(lzx_ctx *c, const double *slice_loc, hipStream_t st)
+{
+    const u32 cnt = c->sx_send_off.empty() ? 0u : c->sx_send_off[c->world];
+    if (cnt == 0) return LZX_OK;
+    hipLaunchKernelGGL(k_sx_pack, dim3((cnt + 255) / 256), dim3(256), 0, st, slice_loc, c->d_sx_send_idx, cnt, c->d_sx_sendbuf);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
 int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_layout)
 {
+    if (c->sparse) {
+        const u64 cnt = (u64)c->world * c->xs0 + c->xc1;
+        hipLaunchKernelGGL(k_relayout_sparse, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, c->stream, io_layout, exchange_layout,
+                           (u32)c->world, c->n_loc_pad, c->xs0, c->d_sx_map, c->xc1);
+        LZX_HIP(hipGetLastError());
+        return LZX_OK;
+    }
     const u64 cnt = (u64)c->world * c->xs;
     hipLaunchKernelGGL(k_relayout, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, c->stream, io_layout, exchange_layout,
                        (u32)c->world, c->n_loc_pad, c->xs, c->xs0);

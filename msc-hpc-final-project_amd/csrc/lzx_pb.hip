@@ -659,6 +659,56 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
 }
 
 
+// One reduced step, lean form (the scatter pass turned out to be bound by its instruction stream, not by memory:
+// with stores, LDS look-ups and the carry all switched off it still took 0.27 of its 0.31 ms, profiles/README.md).
+// Same format, same value order and the same sums as k_pb_scatter's step body, in about half the instructions:
+//   * the eight piece-end flags are the sign bits of the eight half-words: one 16- or 32-bit signed compare each
+//     gives the lane mask that is at once the per-lane flag, the ballot of the plane and the branch condition;
+//   * what a lane hands on (the sum behind its last piece end, or its whole sum) falls out of one running sum that is
+//     reset at every flag, instead of being selected by the position of the last flag;
+//   * no mask of ends per lane, no count-leading-zeros, no per-plane vote.
+__device__ __forceinline__ void pbr_step(const uint4 &c, u32 pos, const double *tile, double *carry, u32 lane, double *val)
+{
+    const u32 w[4] = {c.x, c.y, c.z, c.w};
+    double xv[8];
+    bool f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const u32 h = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+        xv[e] = tile[h & 0x7fffu];
+        // sign of the half-word: the high one is the sign of the 32-bit word
+        f[e] = (e & 1) ? ((int)w[e >> 1] < 0) : ((w[e >> 1] & 0x8000u) != 0u);
+    }
+    const bool has = f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7];
+    // running sum, reset behind every piece end: at the end it is what this lane hands on
+    double t = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        t += xv[e];
+        t = f[e] ? 0.0 : t;
+    }
+    const unsigned long long holders = __ballot(has);
+    const unsigned long long before = holders & ((1ull << lane) - 1ull);
+    const u32 from = before ? 64u - (u32)__clzll((long long)before) : 0u;   // 1 + last holder before this lane
+    atomicAdd(&carry[has ? lane + 1 : from], t);
+    __builtin_amdgcn_wave_barrier();
+    double s = has ? carry[from] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (has) carry[from] = 0.0;
+    double *out = val + pos;
+    u32 done = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s += xv[e];
+        const unsigned long long m = __ballot(f[e]);
+        if (m) {                          // scalar: steps of few long rows have mostly empty planes
+            if (f[e]) out[done + lanes_below(m)] = s;
+            s = f[e] ? 0.0 : s;
+            done += (u32)__popcll(m);
+        }
+    }
+}
+
 // ---- persistent forms of the two passes (default) ---------------------------------------------------------------
 // Both passes above start every work unit cold: a unit record, then the tables it points to, then the first loads --
 // three dependent memory round trips (plus, in the scatter pass, the 128 KiB band) before a workgroup streams, with one
@@ -675,8 +725,9 @@ __global__ void __launch_bounds__(1024)
 k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol,
               const u32 *q_dst, const double *__restrict__ x, u64 xlen, double *val, unsigned long long *stamps)
 {
-    // stamps (debug library only, else null): [4 * workgroup] start, end (100 MHz ticks), units done, restagings
-    unsigned long long t_start = 0;
+    // stamps (debug library only, else null): [4 * workgroup] start, end (100 MHz ticks), units done | restagings << 32,
+    // ticks in the reduced part | ticks in the plain part << 32 (wavefront 0's clock)
+    unsigned long long t_start = 0, t_red = 0, t_plain = 0, t_mark = 0;
     u32 n_done = 0, n_restaged = 0;
     if (stamps) t_start = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) double tile[];   // CB staged values + a zero for padding
@@ -733,44 +784,8 @@ k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *
                 pre[u] = b2 + j < xlen2 ? src[j] : make_double2(0.0, 0.0);
             }
         }
-        {   // ---- reduced steps (see k_pb_scatter)
-            auto body = [&](const uint4 &c, u32 pos) {
-                double xv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = tile[pbr_half(c, e) & 0x7fffu];
-                u32 ends = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ends |= pbr_flag(c, e) << e;
-                const bool has = ends != 0;
-                const int last = has ? 31 - __clz((int)ends) : -1;
-                double tail = 0.0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (e > last) tail += xv[e];
-                const unsigned long long holders = __ballot(has);
-                const unsigned long long before = holders & ((1ull << lane) - 1ull);
-                const u32 from = before ? 64u - (u32)__clzll((long long)before) : 0u;
-                atomicAdd(&carry[has ? lane + 1 : from], tail);
-                __builtin_amdgcn_wave_barrier();
-                double s = has ? carry[from] : 0.0;
-                __builtin_amdgcn_wave_barrier();
-                if (has) carry[from] = 0.0;
-                double *out = val + pos;
-                u32 done = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bool f = (ends >> e) & 1u;
-                    s += xv[e];
-                    const unsigned long long m = __ballot(f);
-                    if (m) {
-                        if (f) {
-                            out[done + lanes_below(m)] = s;
-                            s = 0.0;
-                        }
-                        done += (u32)__popcll(m);
-                    }
-                }
-            };
+        if (stamps) t_mark = wall_clock64();
+        {   // ---- reduced steps (see k_pb_scatter; lean step body: pbr_step)
             u32 s = s_beg + wv;
             for (; s + 3 * W < s_end; s += 4 * W) {
                 uint4 c[4];
@@ -781,10 +796,11 @@ k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *
                     b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) body(c[u], b[u]);
+                for (int u = 0; u < 4; ++u) pbr_step(c[u], b[u], tile, carry, lane, val);
             }
-            for (; s < s_end; s += W) body(scode[(size_t)s * 64 + lane], (u32)__builtin_amdgcn_readfirstlane((int)sbase[s]));
+            for (; s < s_end; s += W) pbr_step(scode[(size_t)s * 64 + lane], (u32)__builtin_amdgcn_readfirstlane((int)sbase[s]), tile, carry, lane, val);
         }
+        if (stamps) { const unsigned long long t = wall_clock64(); t_red += t - t_mark; t_mark = t; }
         // ---- plain quads (see k_pb_scatter)
         for (u32 blk = q_beg + wv * 256u; blk < q_end; blk += W * 256u) {
             const u32 wend = blk + 256u < q_end ? blk + 256u : q_end;
@@ -821,6 +837,7 @@ k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *
                 out[1] = hi;
             }
         }
+        if (stamps) t_plain += wall_clock64() - t_mark;
         if (threadIdx.x == 0) tick[0] = t2;
         __syncthreads();                      // every wavefront is done with the band in LDS
         ++n_done;
@@ -839,8 +856,124 @@ k_pb_scatter2(const u32 *unit, u32 n_units, u32 *queue, u32 qbase, const uint4 *
     if (stamps && threadIdx.x == 0) {
         stamps[4 * blockIdx.x] = t_start;
         stamps[4 * blockIdx.x + 1] = wall_clock64();
-        stamps[4 * blockIdx.x + 2] = n_done;
-        stamps[4 * blockIdx.x + 3] = n_restaged;
+        stamps[4 * blockIdx.x + 2] = n_done | ((unsigned long long)n_restaged << 32);
+        stamps[4 * blockIdx.x + 3] = t_red | (t_plain << 32);
+    }
+}
+
+// Scatter pass, static form (default).  Time stamps of the ticket-driven form (tools/perf_probe.py @st, C3) showed a
+// wavefront working 173 of the 281 us its workgroup is resident: the rest it waits, at the two barriers around every
+// unit, for the slowest of the sixteen wavefronts (their steps differ in pieces) and for the band to be restaged --
+// and a unit is only ~15 steps per wavefront.  Here every workgroup owns ONE contiguous stretch of the scatter order,
+// cut by the host so that all stretches cost the same (bytes read + written, counted per step); a stretch lies in one
+// column band or a few, and inside a band its wavefronts run through all their steps and quads with no barrier at
+// all: per workgroup two or three barrier pairs instead of fourteen, and the band is restaged 2.4 instead of 7 times.
+// segment: {band, first step, last step, first quad, last quad}; seg_begin[w]: first segment of workgroup w.
+template <u32 CB>
+__global__ void __launch_bounds__(1024)
+k_pb_scatter3(const u32 *seg, const u32 *seg_begin, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
+              const double *__restrict__ x, u64 xlen, double *val, unsigned long long *stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // CB staged values + a zero for padding
+    const u32 lane = threadIdx.x & 63;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr u32 W = 1024 / 64;
+    constexpr u32 PRE = CB / 2048;
+    const u64 xlen2 = xlen / 2;
+    unsigned long long t_start = 0, t_red = 0, t_plain = 0, t_mark = 0;
+    if (stamps) t_start = wall_clock64();
+    const u32 i0 = (u32)__builtin_amdgcn_readfirstlane((int)seg_begin[blockIdx.x]);
+    const u32 i1 = (u32)__builtin_amdgcn_readfirstlane((int)seg_begin[blockIdx.x + 1]);
+    if (i0 >= i1) return;
+    if (threadIdx.x < 2) tile[CB + threadIdx.x] = 0.0;
+    for (u32 j = threadIdx.x; j < 16 * 66; j += 1024) tile[CB + 2 + j] = 0.0;   // the wavefronts' carry slots
+    auto fetch_band = [&](u32 band, double2 (&t)[PRE]) {
+        const double2 *src = reinterpret_cast<const double2 *>(x) + (u64)band * (CB / 2);
+        const u64 b2 = (u64)band * (CB / 2);
+#pragma unroll
+        for (u32 u = 0; u < PRE; ++u) {
+            const u32 j = threadIdx.x + u * 1024;
+            t[u] = b2 + j < xlen2 ? src[j] : make_double2(0.0, 0.0);
+        }
+    };
+    double2 pre[PRE];
+    fetch_band((u32)__builtin_amdgcn_readfirstlane((int)seg[5 * i0]), pre);
+#pragma unroll
+    for (u32 u = 0; u < PRE; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = pre[u];
+    __syncthreads();
+    double *carry = tile + CB + 2 + wv * 66;
+    for (u32 i = i0; i < i1; ++i) {
+        const u32 s_beg = (u32)__builtin_amdgcn_readfirstlane((int)seg[5 * i + 1]);
+        const u32 s_end = (u32)__builtin_amdgcn_readfirstlane((int)seg[5 * i + 2]);
+        const u32 q_beg = (u32)__builtin_amdgcn_readfirstlane((int)seg[5 * i + 3]);
+        const u32 q_end = (u32)__builtin_amdgcn_readfirstlane((int)seg[5 * i + 4]);
+        const bool more = i + 1 < i1;
+        if (more) fetch_band((u32)__builtin_amdgcn_readfirstlane((int)seg[5 * (i + 1)]), pre);   // lands while this segment runs
+        if (stamps) t_mark = wall_clock64();
+        {   // ---- reduced steps
+            u32 s = s_beg + wv;
+            for (; s + 3 * W < s_end; s += 4 * W) {
+                uint4 c[4];
+                u32 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                    b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pbr_step(c[u], b[u], tile, carry, lane, val);
+            }
+            for (; s < s_end; s += W) pbr_step(scode[(size_t)s * 64 + lane], (u32)__builtin_amdgcn_readfirstlane((int)sbase[s]), tile, carry, lane, val);
+        }
+        if (stamps) { const unsigned long long t = wall_clock64(); t_red += t - t_mark; t_mark = t; }
+        // ---- plain quads: wavefront w takes the segment's 256-quad blocks w, w + 16, ...
+        for (u32 blk = q_beg + wv * 256u; blk < q_end; blk += W * 256u) {
+            const u32 wend = blk + 256u < q_end ? blk + 256u : q_end;
+            u32 j = blk + lane;
+            for (; j + 3 * 64 < wend; j += 4 * 64) {
+                uint2 c[4];
+                u32 d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    c[u] = q_lcol[j + u * 64];
+                    d[u] = q_dst[j + u * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double2 lo, hi;
+                    lo.x = tile[c[u].x & 0xffffu];
+                    lo.y = tile[c[u].x >> 16];
+                    hi.x = tile[c[u].y & 0xffffu];
+                    hi.y = tile[c[u].y >> 16];
+                    double2 *out = reinterpret_cast<double2 *>(val + d[u]);
+                    out[0] = lo;
+                    out[1] = hi;
+                }
+            }
+            for (; j < wend; j += 64) {
+                const uint2 c = q_lcol[j];
+                double2 lo, hi;
+                lo.x = tile[c.x & 0xffffu];
+                lo.y = tile[c.x >> 16];
+                hi.x = tile[c.y & 0xffffu];
+                hi.y = tile[c.y >> 16];
+                double2 *out = reinterpret_cast<double2 *>(val + q_dst[j]);
+                out[0] = lo;
+                out[1] = hi;
+            }
+        }
+        if (stamps) t_plain += wall_clock64() - t_mark;
+        if (!more) break;
+        __syncthreads();                      // every wavefront is done with the band in LDS
+#pragma unroll
+        for (u32 u = 0; u < PRE; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = pre[u];
+        __syncthreads();
+    }
+    if (stamps && threadIdx.x == 0) {
+        stamps[4 * blockIdx.x] = t_start;
+        stamps[4 * blockIdx.x + 1] = wall_clock64();
+        stamps[4 * blockIdx.x + 2] = (i1 - i0) | ((unsigned long long)(i1 - i0 - 1) << 32);
+        stamps[4 * blockIdx.x + 3] = t_red | (t_plain << 32);
     }
 }
 
@@ -1048,6 +1181,8 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_items);
     pb_free(c->d_pb_items2);
     pb_free(c->d_pb_wg_begin);
+    pb_free(c->d_pb_seg);
+    pb_free(c->d_pb_seg_begin);
     pb_free(c->d_pb_stamps);
     pb_free(c->d_pb_queue);
     pb_free(c->d_pb_multi);
@@ -1167,6 +1302,102 @@ int pb_units(lzx_ctx *c, hipStream_t st, const std::vector<u32> &sstart, const s
     LZX_TRY(pb_alloc(&c->d_pb_unit, units.size()));
     if (!units.empty())
         LZX_HIP(hipMemcpyAsync(c->d_pb_unit, units.data(), sizeof(u32) * units.size(), hipMemcpyHostToDevice, st));
+    LZX_HIP(hipStreamSynchronize(st));
+    return LZX_OK;
+}
+
+// Static scatter schedule: the scatter order (band by band: a band's steps, then its quads) is cut into `groups`
+// stretches of equal cost -- bytes read + written: per step its 1 KiB of codes + 8 B per piece, per quad 12 B + 32 B --
+// one per workgroup; a stretch is stored as segments {band, steps, quads}, one per band it touches.  Two schedules:
+// the bands of chunk 0 of the exchange (all of them without the two-chunk exchange) and the rest.
+int pb_segments(lzx_ctx *c, hipStream_t st, const std::vector<u32> &sstart, const std::vector<u32> &qstart, u32 nb, u32 nsteps)
+{
+    std::vector<u32> cnt(nsteps, 0u);
+    if (nsteps) {
+        u32 *d_cnt = nullptr;
+        LZX_TRY(pb_alloc(&d_cnt, nsteps));
+        hipLaunchKernelGGL(k_pbr_count, dim3(nsteps), dim3(64), 0, st, c->d_pbr_code, d_cnt);
+        hipError_t e = hipMemcpyAsync(cnt.data(), d_cnt, sizeof(u32) * nsteps, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_cnt);
+        LZX_HIP(e);
+    }
+    const u32 per_cu = c->pb_cb == 8192 ? 2u : 1u;
+    const u32 groups_max = (u32)c->cu_count * per_cu;
+    u32 b_split = nb;   // first band of the second schedule
+    if (c->overlap) {
+        const u64 chunk0_end = (u64)c->world * c->xs0;
+        b_split = 0;
+        while (b_split < nb && ((u64)b_split + 1) * c->pb_cb <= chunk0_end) ++b_split;
+    }
+    std::vector<u32> segs, begin;
+    auto band_steps = [&](u32 b, u32 &s0, u32 &s1) { s0 = sstart.empty() ? 0 : sstart[b]; s1 = sstart.empty() ? 0 : sstart[b + 1]; };
+    auto band_quads = [&](u32 b, u32 &q0, u32 &q1) { q0 = qstart.empty() ? 0 : qstart[b]; q1 = qstart.empty() ? 0 : qstart[b + 1]; };
+    constexpr u64 QUAD_COST = 44;
+    auto step_cost = [&](u32 s) { return 1024ull + 8ull * cnt[s] + 64ull; };
+    for (int part = 0; part < 2; ++part) {
+        const u32 b0 = part == 0 ? 0 : b_split, b1 = part == 0 ? b_split : nb;
+        u64 total = 0;
+        for (u32 b = b0; b < b1; ++b) {
+            u32 s0, s1, q0, q1;
+            band_steps(b, s0, s1);
+            band_quads(b, q0, q1);
+            for (u32 s = s0; s < s1; ++s) total += step_cost(s);
+            total += (u64)(q1 - q0) * QUAD_COST;
+        }
+        const u32 groups = total ? (u32)std::min<u64>(groups_max, std::max<u64>(1, total / 65536)) : 0;
+        c->pb_seg_groups[part] = groups;
+        c->pb_seg_first[part] = (u32)begin.size();
+        if (!groups) { begin.push_back((u32)(segs.size() / 5)); continue; }
+        u64 done = 0;
+        u32 g = 0;   // current group; its share ends at total * (g + 1) / groups
+        begin.push_back((u32)(segs.size() / 5));
+        auto limit = [&]() { return total * (u64)(g + 1) / groups; };
+        auto close_group = [&]() {
+            while (g + 1 < groups && done >= limit()) {
+                ++g;
+                begin.push_back((u32)(segs.size() / 5));
+            }
+        };
+        for (u32 b = b0; b < b1; ++b) {
+            u32 s0, s1, q0, q1;
+            band_steps(b, s0, s1);
+            band_quads(b, q0, q1);
+            u32 s = s0, q = q0;
+            while (s < s1 || q < q1) {
+                // the part of this band that still fits the current group: steps first, then quads
+                u32 se = s;
+                while (se < s1 && (g + 1 == groups || done < limit())) done += step_cost(se++);
+                u32 qe = q;
+                if (se == s1 && q < q1) {
+                    if (g + 1 == groups) {
+                        done += (u64)(q1 - q) * QUAD_COST;
+                        qe = q1;
+                    } else if (done < limit()) {
+                        const u64 room = limit() - done;
+                        const u32 take = (u32)std::min<u64>(q1 - q, (room + QUAD_COST - 1) / QUAD_COST);
+                        done += (u64)take * QUAD_COST;
+                        qe = q + take;
+                    }
+                }
+                if (se > s || qe > q) {
+                    segs.push_back(b); segs.push_back(s); segs.push_back(se); segs.push_back(q); segs.push_back(qe);
+                }
+                s = se;
+                q = qe;
+                close_group();
+            }
+        }
+        while (g + 1 < groups) {   // groups the rounding left empty
+            ++g;
+            begin.push_back((u32)(segs.size() / 5));
+        }
+        begin.push_back((u32)(segs.size() / 5));   // end of the last group of this part
+    }
+    LZX_TRY(pb_alloc(&c->d_pb_seg, segs.size()));
+    LZX_TRY(pb_alloc(&c->d_pb_seg_begin, begin.size()));
+    if (!segs.empty()) LZX_HIP(hipMemcpyAsync(c->d_pb_seg, segs.data(), sizeof(u32) * segs.size(), hipMemcpyHostToDevice, st));
+    LZX_HIP(hipMemcpyAsync(c->d_pb_seg_begin, begin.data(), sizeof(u32) * begin.size(), hipMemcpyHostToDevice, st));
     LZX_HIP(hipStreamSynchronize(st));
     return LZX_OK;
 }
@@ -1410,6 +1641,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     }
     ar.drop(d_plcol); ar.drop(d_qcband);
     LZX_TRY(pb_units(c, st, sstart, qstart, nb, unit_cap));
+    LZX_TRY(pb_segments(c, st, sstart, qstart, nb, nsteps));
     LZX_HIP(hipGetLastError());
 
     // 6. conflict-free LDS slots for the gather pass
@@ -1567,12 +1799,13 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
 }
 
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
-                  hipEvent_t v_ready)
+                  hipEvent_t v_ready, int phases)
 {
+    const bool do_scatter = phases & 1, do_gather = phases & 2;
     if (!c->pb) {
         // no blocked tables on this rank: still order the stream behind the second chunk of the exchange, so that the next
         // collective on the main stream never starts while that all-gather is in flight on the exchange stream
-        if (chunk1_ready) LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
+        if (chunk1_ready && do_scatter) LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
         return LZX_OK;
     }
     const size_t lds1 = ((size_t)c->pb_cb + 2 + 16 * 66) * sizeof(double);
@@ -1591,8 +1824,24 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     auto kern2 = c->pb_cb == 8192 ? k_pb_scatter2<8192> : k_pb_scatter2<LZX_PB_CB>;
     if (c->pb_units && persistent)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1p));
+    auto kern3 = c->pb_cb == 8192 ? k_pb_scatter3<8192> : k_pb_scatter3<LZX_PB_CB>;
+    const bool fixed = persistent && c->pb_persist_opt != 2;   // 2 = the ticket-driven form (debug knob)
+    if (c->pb_units && fixed)
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1p));
     auto scatter = [&](u32 u0, u32 u1) {
         if (u1 <= u0) return;
+        if (fixed) {
+            // schedule 0 = the bands of chunk 0 (units [0, pb_units0)), schedule 1 = the rest; a call for all units runs both
+            for (int part = 0; part < 2; ++part) {
+                const bool wanted = part == 0 ? u0 == 0 : u1 == c->pb_units && c->pb_units0 < c->pb_units;
+                const u32 grid = c->pb_seg_groups[part];
+                if (!wanted || !grid) continue;
+                hipLaunchKernelGGL(kern3, dim3(grid), dim3(1024), lds1p, c->stream, c->d_pb_seg, c->d_pb_seg_begin + c->pb_seg_first[part],
+                                   c->d_pbr_code, c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen,
+                                   c->d_pb_val, c->d_pb_stamps ? c->d_pb_stamps + 4096 * part : nullptr);
+            }
+            return;
+        }
         if (persistent) {
             const u32 q = u0 == 0 ? 0u : 1u, n = u1 - u0;
             const u32 grid = std::min<u32>(n, (u32)c->cu_count * (c->pb_cb == 8192 ? 2u : 1u));
@@ -1606,8 +1855,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                            c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val, ablate);
     };
     // column bands of chunk 0 first; the rest once the second chunk of the exchange has arrived
-    if (c->phase_mask_opt & 4) {
-        // experiment: gather pass alone (reads values a previous SpMV left)
+    if ((c->phase_mask_opt & 4) || !do_scatter) {
+        // experiment: gather pass alone (reads values a previous SpMV left); or the scatter pass was launched earlier
     } else if (chunk1_ready) {
         scatter(0, c->pb_units0);
         LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
@@ -1615,7 +1864,11 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     } else {
         scatter(0, c->pb_units);
     }
-    if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
+    if (c->trace && do_scatter) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
+    if (!do_gather) {
+        LZX_HIP(hipGetLastError());
+        return LZX_OK;
+    }
     if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);
     LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather),

@@ -49,9 +49,15 @@ def test_c2_full_size(pkg, oracle):
 
 def test_c2_k50_against_oracle(pkg, oracle):
     """BASELINE C2 at its own Krylov dimension, k = 50, against the oracle.  lambda_max of this graph is ~1e3, so e^A x
-    overflows fp64 (as the reference's own dense runs report NaN); the north-star criterion is checked on the
-    overflow-safe, converged functional of test_gpu_parity.shift_weights (e^(s (A - theta_max)) x, s theta_max = 40),
-    and every one of the 50 columns of the basis is pinned by the three-term recurrence against the ORACLE's SpMV."""
+    overflows fp64 (as the reference's own dense runs report NaN); the criterion is checked on e^(A - theta_max) x =
+    e^A x / e^theta_max, the exponent shifted by the largest Ritz value on both sides, and on the functional
+    e^(s (A - theta_max)) x with s theta_max = 40 (test_gpu_parity.shift_weights).  Fifty steps without
+    re-orthogonalisation on this graph are NOT reproducible to 1e-10 by the serial/ algorithm itself: the oracle run
+    on the same graph with its vertices relabelled (identical mathematics, other summation orders) differs from the
+    oracle by 3e-8 / 8e-10 in these two quantities (alpha_1 already by 6e-12 relative).  So the tolerance is the north
+    star's 1e-10 or four times the oracle's own relabelling difference, whichever is larger -- measured here, not
+    assumed -- and every one of the 50 columns of the basis is pinned by the three-term recurrence against the
+    ORACLE's SpMV at 1e-12."""
     from test_gpu_parity import REL_INF_TOL, check_recurrence, rel_inf, shift_weights
     O = oracle
     eng = pkg.Engine(0)
@@ -59,14 +65,25 @@ def test_c2_k50_against_oracle(pkg, oracle):
     rp, ci = eng.get_graph_csr()
     n, k = 1 << 20, 50
     a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, np.ones(n), q_colmajor=True)
+    # the oracle against itself: same graph, vertices relabelled by a seeded permutation
+    perm = np.random.default_rng(1).permutation(n).astype(np.uint64)
+    rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp.astype(np.int64)))
+    rp2, ci2 = O.csr_from_keys(n, (perm[rows] << np.uint64(32)) | perm[ci.astype(np.int64)])
+    a_p, b_p, Q_p, xn_p = O.lanczos(rp2, ci2, k, np.ones(n), q_colmajor=True)
     a, b, Q, xn, st = eng.lanczos(np.ones(n), k)
     assert xn == xn_ref and st["iters"] == k
     assert np.isfinite(a).all() and np.isfinite(b).all()
     check_recurrence(O, rp, ci, a, b, Q, "c2_k50")
-    ref = shift_weights(O, a_ref, b_ref, xn_ref) @ Q_ref
-    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
-    assert rel_inf(shift_weights(O, a, b, xn) @ Q, ref) <= REL_INF_TOL
-    assert rel_inf(eng.multout(shift_weights(O, a, b, xn)), ref) <= REL_INF_TOL
+    for cap in (None, 40.0):
+        ref = shift_weights(O, a_ref, b_ref, xn_ref, cap=cap) @ Q_ref
+        assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+        own = rel_inf((shift_weights(O, a_p, b_p, xn_p, cap=cap) @ Q_p)[perm.astype(np.int64)], ref)
+        tol = max(REL_INF_TOL, 4.0 * own)
+        got_host = rel_inf(shift_weights(O, a, b, xn, cap=cap) @ Q, ref)
+        got_dev = rel_inf(eng.multout(shift_weights(O, a, b, xn, cap=cap)), ref)
+        print(f"C2 k=50 cap={cap}: oracle vs relabelled oracle {own:.2e}; engine vs oracle {got_host:.2e} (host multOut) "
+              f"{got_dev:.2e} (device multOut); tolerance {tol:.1e}")
+        assert got_host <= tol and got_dev <= tol, (cap, own, got_host, got_dev)
     eng.close()
 
 
@@ -84,21 +101,27 @@ def test_eight_ranks_in_process_c2(pkg, oracle):
     ref = shift_weights(O, a_ref, b_ref, xn_ref) @ Q_ref
     x = np.random.default_rng(8).random(n)
     y_ref = O.spmv(rp, ci, x)
-    for overlap in (1, 0):
-        grp = pkg.LocalGroup([0] * 8, overlap_exchange=overlap)
+    recv = {}
+    for overlap, sparse in ((1, 1), (1, 0), (0, 1)):
+        grp = pkg.LocalGroup([0] * 8, propagation_blocking=1, overlap_exchange=overlap, sparse_exchange=sparse)   # (a rank's eighth of C2 is below the size at which the blocked SpMV switches itself on)
         grp.set_graph_csr(rp, ci)
         gi = grp.engines[5].info()
         assert gi["world"] == 8 and gi["rank"] == 5 and gi["pb_entries"] > 0
         assert (gi["exchange_chunk0"] > 0) == (overlap == 1)
+        recv[(overlap, sparse)] = gi["exchange_recv"]
         assert 0 < gi["exchange_slice"] <= -(-gi["active_vertices"] // 8 // 64) * 64 + 64
         assert abs(gi["nnz_local"] * 8 - gi["nnz"]) <= 0.02 * gi["nnz"]          # rows dealt by degree rank: balanced
         assert np.allclose(grp.spmv(x), y_ref, rtol=1e-13, atol=0)
         a, b, Q, xn, st = grp.lanczos(np.ones(n), k)
         assert xn == xn_ref
-        check_leading_coefficients(a, b, a_ref, b_ref, ("local8", overlap))
+        check_leading_coefficients(a, b, a_ref, b_ref, ("local8", overlap, sparse), n=n)
         check_recurrence(O, rp, ci, a, b, Q, ("local8", overlap))
         assert rel_inf(grp.multout(shift_weights(O, a, b, xn)), ref) <= REL_INF_TOL
         grp.close()
+    # the sparse second chunk: a rank receives only what its rows reference (dense: 7 slices of the active prefix)
+    assert recv[(1, 0)] == recv[(0, 1)] == 7 * gi["exchange_slice"]
+    assert recv[(1, 1)] < 0.8 * recv[(1, 0)], recv
+    print("doubles received per rank and iteration at 8 ranks on C2: dense", recv[(1, 0)], "sparse", recv[(1, 1)])
 
 
 def test_c3_full_size_properties(pkg, oracle):

@@ -40,27 +40,33 @@ def pipeline_ref(O, rp, ci, k, x0):
     return a, b, Q, xn, O.mult_out(np.ascontiguousarray(Q.T), V, lam, xn)
 
 
-def shift_weights(O, a, b, xn):
+def shift_weights(O, a, b, xn, cap=40.0):
     """t = V (e^(s (lambda - lambda_max)) .* ||x|| V[0,:]): multOut's small k x k part (parallel-final/lib/multiplyOut.cu:30-40)
     with the exponent shifted by the largest Ritz value, so that e^(s (A - theta_max)) x = Q t is finite on every graph
     (e^A x itself overflows fp64 on the hub-heavy ones, as the reference's own runs report), and with s = min(1, 40 /
     theta_max): where theta_max is in the hundreds a k-step Krylov approximation of e^A x has not converged to 1e-10
     (two correct fp64 runs then differ by more than that: the plain-mode engine and the oracle do on rmat_hub at k = 20,
     4.7e-10), while e^(sA) x with s theta_max <= 40 has, so it pins basis and coefficients at the north star's 1e-10.
-    On every graph with theta_max <= 40 (all fixtures, C1) s = 1: the centrality vector itself, scaled."""
+    On every graph with theta_max <= 40 (all fixtures, C1) s = 1: the centrality vector itself, scaled.
+    cap = None: s = 1 whatever theta_max is (e^(A - theta_max) x: at large k, where the top Ritz pair has converged)."""
     lam, V = O.eigen(a, b)
-    s = min(1.0, 40.0 / max(lam.max(), 1e-300))
+    s = 1.0 if cap is None else min(1.0, cap / max(lam.max(), 1e-300))
     return V @ (np.exp(s * (lam - lam.max())) * (xn * V[0, :]))
 
 
-def check_leading_coefficients(a, b, a_ref, b_ref, name):
+def check_leading_coefficients(a, b, a_ref, b_ref, name, n=0):
     """The Lanczos recurrence amplifies rounding-level differences (here: the order of the alpha / beta
     reductions) once Ritz values converge, so late alpha_j / beta_j of two correct fp64 runs differ freely
     -- the reference's own CPU and GPU paths do.  What is pinned coefficient-wise is the
-    start of the recurrence; the centrality vector, which is what the method is for, is pinned at 1e-10."""
+    start of the recurrence; the centrality vector, which is what the method is for, is pinned at 1e-10.
+    n: vertices, for the tolerance of beta_0 on large graphs -- the reference's norm is ONE left-to-right sum
+    (serial/lib/lanczos.cc:157-163); with x0 = ones it adds ~n/2 identical tiny squares (the vertices without
+    edges) to an accumulator that the hub vertices, first in R-MAT order, made large, and identical addends round the
+    same way every time: a systematic error of up to n * eps / 2 relative (measured 1.1e-11 on the 1 M-vertex C2
+    graph, where the engine's tree-shaped sums are the accurate side)."""
     assert abs(a[0] - a_ref[0]) <= 1e-12 * abs(a_ref[0]), name
     if len(b):
-        assert abs(b[0] - b_ref[0]) <= 1e-12 * abs(b_ref[0]), name
+        assert abs(b[0] - b_ref[0]) <= max(1e-12, n * 1.2e-16) * abs(b_ref[0]), name
     if len(a) > 1:
         assert abs(a[1] - a_ref[1]) <= 1e-10 * max(abs(a_ref[1]), abs(a_ref[0])), name
 
@@ -228,13 +234,15 @@ def test_local_group_overlapped_exchange(oracle, pkg):
     results = []
     # (overlap, minimum length of a reduced run): the runs of this graph are ~270 entries long, so the default (384)
     # leaves them plain and 128 makes them reduced, items of 2048 values cut every row band into several
-    for overlap, min_run, lazy in ((1, 384, 1), (0, 384, 1), (1, 128, 1), (1, 384, 0)):
+    # the second chunk travels sparse (each peer gets what its rows reference) except in the last variant
+    for overlap, min_run, lazy, sparse in ((1, 384, 1, 1), (0, 384, 1, 1), (1, 128, 1, 1), (1, 384, 0, 1), (1, 384, 1, 0)):
         grp = pkg.LocalGroup([0, 0, 0], propagation_blocking=1, hub_entries=1024, overlap_exchange=overlap, pb_reduce=min_run,
-                             pb_target=2048 if min_run == 128 else -1, lazy_normalisation=lazy)
+                             pb_target=2048 if min_run == 128 else -1, lazy_normalisation=lazy, sparse_exchange=sparse)
         grp.set_graph_csr(rp, ci)
         gi = grp.engines[1].info()
         assert gi["pb_entries"] > 0 and 0 < gi["exchange_slice"] <= -(-gi["active_vertices"] // 3 // 64) * 64 + 64
         assert (gi["exchange_chunk0"] > 0) == (overlap == 1)
+        assert (gi["exchange_recv"] < 2 * gi["exchange_slice"]) == (overlap == 1 and sparse == 1), gi
         assert (gi["pb_reduced_entries"] > gi["pb_entries"] // 2) == (min_run == 128), (overlap, min_run, gi)
         assert np.allclose(grp.spmv(x), y_ref, rtol=1e-13, atol=0)
         a, b, Q, xn, st = grp.lanczos(x0, k)

@@ -43,6 +43,14 @@ if __name__ == "__main__":
     if "diag2" in sets:
         opts = [dict(pb_stamps=1), dict(pb_stamps=1, pb_gather_waves=4), dict(pb_stamps=1, hub_entries=2), dict(pb_stamps=1, hub_entries=1024),
                 dict(pb_stamps=1, hub_entries=4096), dict(pb_stamps=1, hub_entries=8192), dict(pb_stamps=1, hub_entries=2, pb_gather_waves=4)]
+    if "st2" in sets:
+        opts = [dict(pb_stamps=1), dict(pb_stamps=1, pb_persistent=2), dict(pb_stamps=1, pb_persistent=0), dict(), dict(pb_persistent=2), dict()]
+    if "st" in sets:
+        opts = [dict(pb_stamps=1), dict(pb_stamps=1, pb_order=0), dict(pb_stamps=1, pb_reduce=0), dict(pb_stamps=1, pb_reduce=128), dict(pb_stamps=1)]
+    if "order" in sets:
+        opts = [dict(), dict(pb_order=0), dict(pb_stamps=1), dict(pb_order=0, pb_stamps=1), dict(), dict(pb_order=0)]
+    if "abl" in sets:
+        opts = [dict(pb_persistent=0)]
     if "persist" in sets:
         opts = [dict(), dict(pb_persistent=0), dict(), dict(pb_persistent=0)]
     if "plain" in sets:
