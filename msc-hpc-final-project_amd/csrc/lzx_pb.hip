@@ -1819,7 +1819,9 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
 #endif
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    const bool persistent = c->pb_persist_opt != 0 && !ablate;
+    // default: one workgroup per unit / static item lists (k_pb_scatter, k_pb_gather).  The persistent forms below are
+    // kept for the record of DESIGN.md section 3 (debug knob pb_persistent: 1 static schedule, 2 tickets): none was faster.
+    const bool persistent = c->pb_persist_opt > 0 && !ablate;
     const size_t lds1p = lds1 + 16;
     auto kern2 = c->pb_cb == 8192 ? k_pb_scatter2<8192> : k_pb_scatter2<LZX_PB_CB>;
     if (c->pb_units && persistent)

@@ -50,14 +50,61 @@ def test_handle_reuse_and_growth(pkg, oracle):
     eng.close()
 
 
+def test_prepared_state_is_voided_by_other_calls(pkg, oracle):
+    """lzx_lanczos_prepare_f64 leaves q_0 in work buffers; handing over another graph frees them, and
+    lzx_spmv_f64 / lzx_multout_f64 / lzx_bench_spmv overwrite them.  Each of these now voids the preparation, so a
+    following lzx_lanczos_run is an LZX_ERR_STATE instead of a device fault or silently wrong coefficients."""
+    O = oracle
+    rp, ci = O.gen_er(3000, 20000, 5)
+    rp2, ci2 = O.gen_er(1200, 9000, 6)
+    eng = pkg.Engine(0)
+    eng.set_graph_csr(rp, ci)
+    eng.lanczos_prepare(np.ones(3000), 6)
+    eng.set_graph_csr(rp2, ci2)                                  # frees the basis the preparation sized
+    with pytest.raises(pkg.LzxError):
+        eng.lanczos_run()
+    a_ref, b_ref, _, _, _ = eng.lanczos(np.ones(1200), 6)
+    for clobber in (lambda: eng.spmv(np.ones(1200)), lambda: eng.bench_spmv(1)):
+        eng.lanczos_prepare(np.ones(1200), 6)
+        clobber()
+        with pytest.raises(pkg.LzxError):
+            eng.lanczos_run()
+    eng.lanczos_prepare(np.ones(1200), 6)
+    with pytest.raises(pkg.LzxError):
+        eng.multout(np.ones(3))                                  # a preparation invalidates the previous basis at once
+    eng.lanczos_prepare(np.ones(1200), 6)                        # the straight sequence still works, same numbers
+    eng.lanczos_run()
+    a, b, _ = eng.lanczos_fetch(6)
+    assert np.array_equal(a, a_ref) and np.array_equal(b, b_ref)
+    with pytest.raises(pkg.LzxError):
+        eng.lanczos_run()                                        # a preparation is consumed by its run
+    eng.close()
+
+
 def test_csr_validation(pkg):
     eng = pkg.Engine(0)
+    with pytest.raises(pkg.LzxError):                             # row_ptr decreases (sums still match)
+        eng.set_graph_csr(np.array([0, 2, 1, 3], dtype=np.uint64), np.array([1, 2, 0], dtype=np.uint32))
+    with pytest.raises(pkg.LzxError):                             # a column index >= n would index the reshaping tables out of bounds
+        eng.set_graph_csr(np.array([0, 1, 2, 3], dtype=np.uint64), np.array([1, 7, 0], dtype=np.uint32))
+    with pytest.raises(pkg.LzxError):                             # an edge endpoint >= n in the device ingest
+        eng.set_graph_edges(4, np.array([0, 9], dtype=np.uint32), np.array([1, 2], dtype=np.uint32))
+    eng.set_graph_csr(np.array([0, 1, 2, 2], dtype=np.uint64), np.array([1, 0], dtype=np.uint32))   # still usable afterwards
+    assert np.array_equal(eng.spmv(np.array([1.0, 2.0, 3.0])), np.array([2.0, 1.0, 0.0]))
     with pytest.raises(pkg.LzxError):
         eng.set_graph_csr(np.array([0, 1, 3], dtype=np.uint64), np.array([1, 0], dtype=np.uint32))   # row_ptr[n] != nnz
     with pytest.raises(pkg.LzxError):
         eng.set_graph_csr(np.array([1, 1, 2], dtype=np.uint64), np.array([1, 0], dtype=np.uint32))   # row_ptr[0] != 0
+    fresh = pkg.Engine(0)                                        # options go in before the graph
+    fresh.set_option("hub_entries", 4096)
     with pytest.raises(pkg.LzxError):
-        eng.set_option("no_such_option", 1)
+        fresh.set_option("no_such_option", 1)
+    with pytest.raises(pkg.LzxError):
+        fresh.set_option("pb_reduce", 1)                         # an experiment knob: liblzx_dbg.so only
+    fresh.close()
+    dbg = pkg.Engine(0, pb_reduce=1)                             # ... which the package loads when asked for one
+    assert dbg.L is not eng.L
+    dbg.close()
     with pytest.raises(pkg.LzxError):
         pkg.Engine(99)                                            # no such device
     eng.close()

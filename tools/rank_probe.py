@@ -14,7 +14,7 @@ src.gen_rmat(scale, n, draws, 1234)
 rp, ci = src.get_graph_csr()
 src.close()
 for world in (1, 2, 4, 8):
-    for opts in (dict(propagation_blocking=0), dict()):
+    for opts in (dict(propagation_blocking=0), dict(sparse_exchange=0), dict()):
         if world == 1:
             eng = pkg.Engine(0, **opts)
             eng.set_graph_csr(rp, ci)
@@ -28,5 +28,6 @@ for world in (1, 2, 4, 8):
         gi = e0.info()
         avg, mn = e0.bench_spmv(10)
         print(f"world={world} {opts} rows_local={gi['rows_local']} nnz_local={gi['nnz_local']} pb={gi['pb_entries']} reduced={gi['pb_reduced_entries']} values={gi['pb_values']} "
+              f"exchange: slice {gi['exchange_slice']} chunk0 {gi['exchange_chunk0']} received per iteration {gi['exchange_recv']} doubles = {8 * gi['exchange_recv'] / 1e6:.1f} MB | "
               f"spmv min {mn:.4f} ms (x{world} = {mn * world:.3f})", flush=True)
         (grp or e0).close()
