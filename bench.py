@@ -70,7 +70,7 @@ def cpu_baseline(eng, O, budget_s: float = 20.0):
     O.lanczos(rp, ci, k, x0, want_q=False)
     dt = time.perf_counter() - t
     return {"value": k / dt, "unit": "iter/s", "cores": 1, "kind": "port",
-            "sample": f"{k} Lanczos iterations of the same graph (oracle/lanczos_oracle.c, -O2, 1 thread, "
+            "sample": f"{k} Lanczos iterations of the same graph (oracle/lanczos_oracle.c, -O3 -ffp-contract=off as the reference builds, 1 thread, "
                       f"{dt:.1f} s; host has {os.cpu_count()} hardware threads)"}
 
 

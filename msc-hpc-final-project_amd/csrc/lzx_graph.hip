@@ -419,7 +419,7 @@ int lzx_graph_prepare(lzx_ctx *c)
 
     // ---- 1b. sparse exchange of chunk 1: this rank's packed x layout and its send lists (see k_sx_mark) ----
     c->sparse = false;
-    if (c->overlap && world > 1 && c->sparse_opt != 0 && c->xs > c->xs0) {
+    if (c->overlap && (world > 1 || c->force_multi) && c->sparse_opt != 0 && c->xs > c->xs0) {
         const u32 L1 = c->xs - c->xs0;
         const u64 cnt = (u64)world * L1;
         uint8_t *d_ref = nullptr, *d_want = nullptr;
@@ -892,7 +892,7 @@ extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
     o->reserved_ = 0;
     o->exchange_chunk0 = c->overlap ? c->xs0 : 0;
     o->exchange_recv = 0;
-    if (c->world > 1) {
+    if (c->world > 1 || c->sparse) {
         o->exchange_recv = (u64)(c->world - 1) * c->xs;
         if (c->sparse)
             o->exchange_recv = (u64)(c->world - 1) * c->xs0 + c->xc1 - (c->sx_recv_off[c->rank + 1] - c->sx_recv_off[c->rank]);

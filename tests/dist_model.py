@@ -7,10 +7,14 @@ import torch
 import torch.distributed as dist
 
 
-def run_rank(pkg_partition, row_ptr, col_idx, x0, k, xs0=None, lazy=False):
+def run_rank(pkg_partition, row_ptr, col_idx, x0, k, xs0=None, lazy=False, sparse=False):
     """Returns (alpha, beta, gathered full-length q vectors (k, n) in the caller's order) on every rank.
     lazy: the product's default at N > 1 -- the unnormalised vector is exchanged and ONE 2-double all-reduce per
-    iteration carries u.(A u) and ||u||^2 (csrc/lzx_kernels.hip: k_lazy_update)."""
+    iteration carries u.(A u) and ||u||^2 (csrc/lzx_kernels.hip: k_lazy_update).
+    sparse (with xs0): chunk 1 travels point to point -- every rank derives, from the whole graph it holds, which
+    chunk-1 entries of each peer its rows reference and which of its own entries each peer's rows reference, packs per
+    peer and sends (csrc/lzx_graph.hip: k_sx_mark; csrc/lzx_comm.hip: lzx_comm_sparse_chunk1).  Entries nobody on
+    this rank references stay 0 in its copy: they are never read."""
     P = pkg_partition
     world, rank = dist.get_world_size(), dist.get_rank()
     n = len(row_ptr) - 1
@@ -46,12 +50,50 @@ def run_rank(pkg_partition, row_ptr, col_idx, x0, k, xs0=None, lazy=False):
         dist.all_gather(outs, torch.from_numpy(np.ascontiguousarray(loc[first:first + count])))
         return torch.cat(outs).numpy()
 
+    # sparse chunk 1: what I need from every peer and what every peer needs from me, from the graph alone
+    L1 = X - X0
+    need = want = None
+    if sparse and L1 > 0:
+        c1 = world * X0
+        need = [np.zeros(L1, dtype=bool) for _ in range(world)]      # need[r][l]: my rows reference peer r's entry X0 + l
+        want = [np.zeros(L1, dtype=bool) for _ in range(world)]      # want[p][l]: rank p's rows reference MY entry X0 + l
+        for p in range(world):
+            for o in P.local_vertices(order, world, p):
+                cols = pos_of_old[col_idx[rp[o]:rp[o + 1]].astype(np.int64)]
+                cols = cols[cols >= c1] - c1
+                owner, l = cols // L1, cols % L1
+                if p == rank:
+                    for r in range(world):
+                        need[r][l[owner == r]] = True
+                want[p][l[owner == rank]] = True
+
     def exchange(loc):
         """chunk 0 of every slice, then chunk 1: two all-gathers into one buffer (in the product the SpMV starts on
-        chunk 0 while chunk 1 is still travelling)"""
+        chunk 0 while chunk 1 is still travelling); or chunk 1 packed per peer and sent point to point"""
         if X0 == X:
             return allgather(loc, X)
-        return np.concatenate([allgather(loc, X0), allgather(loc, X - X0, X0)])
+        if need is None:
+            return np.concatenate([allgather(loc, X0), allgather(loc, L1, X0)])
+        head = allgather(loc, X0)
+        tail = np.zeros(world * L1)
+        mine1 = loc[X0:X0 + L1]
+        tail[rank * L1:(rank + 1) * L1][need[rank]] = mine1[need[rank]]          # my own segment: no transport
+        ops, bufs = [], {}
+        for peer in range(world):
+            if peer == rank:
+                continue
+            send = torch.from_numpy(np.ascontiguousarray(mine1[want[peer]]))
+            bufs[peer] = torch.empty(int(need[peer].sum()), dtype=torch.float64)
+            if send.numel():
+                ops.append(dist.P2POp(dist.isend, send, peer))
+            if bufs[peer].numel():
+                ops.append(dist.P2POp(dist.irecv, bufs[peer], peer))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for peer, b in bufs.items():
+            tail[peer * L1:(peer + 1) * L1][need[peer]] = b.numpy()
+        return np.concatenate([head, tail])
 
     xn = np.sqrt(np.sum(x0 * x0))
     q = np.zeros(L)

@@ -55,6 +55,12 @@ def _worker(rank, world, port, out_dir):
     assert abs(a3[1] - alpha[1]) <= 1e-11 * max(abs(alpha[1]), abs(alpha[0]))
     assert np.abs(Q3[:3] - Q[:3]).max() <= 1e-12
     np.savez(os.path.join(out_dir, f"lazy{rank}.npz"), alpha=a3, beta=b3, Q=Q3)
+    # the sparse second chunk (the product's default with the two-chunk exchange): every peer receives only what its
+    # rows reference, both sides derived from the graph -- the numbers must not change at all
+    a4, b4, Q4, _ = dist_model.run_rank(P, rp, ci, np.ones(n), k, xs0=128, lazy=True, sparse=True)
+    assert np.array_equal(a4, a3) and np.array_equal(b4, b3) and np.array_equal(Q4, Q3)
+    a5, b5, Q5, _ = dist_model.run_rank(P, rp, ci, np.ones(n), k, xs0=128, sparse=True)
+    assert np.array_equal(a5, alpha) and np.array_equal(b5, beta) and np.array_equal(Q5, Q)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == world

@@ -258,6 +258,25 @@ def test_local_group_overlapped_exchange(oracle, pkg):
     assert abs(results[0][1][0] - results[1][1][0]) <= 1e-13 * abs(results[1][1][0])
 
 
+def test_rccl_several_gpus():
+    """The real thing where the box has it: 2 (or up to 4) ranks, one GPU each, RCCL over xGMI -- all exchange modes
+    against the oracle (tests/rccl_ranks.py).  Skipped on a one-GPU box; the in-process groups above and
+    test_rccl_world1 below cover the same code on one GPU."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    gpus = torch.cuda.device_count()
+    if gpus < 2:
+        pytest.skip("needs at least 2 GPUs")
+    world = min(gpus, 4)
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(here, "rccl_ranks.py")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and f"RCCL_RANKS_OK {world}" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_rccl_world1(oracle, pkg):
     """RCCL transport at world = 1: communicator creation, symbol resolution, stream plumbing -- and, with the test hook
     `exchange_at_world_1`, the several-rank loop itself on that communicator: ncclAllReduce of two doubles, ncclAllGather
