@@ -194,6 +194,10 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           SpMV (default: allowed)
  *   "sparse_exchange"       1 / 0: with the two-chunk exchange, send each peer only the entries of the second chunk its rows
  *                           reference (default 1)
+ *   "exchange_fp32"         1: several ranks exchange the new Lanczos vector rounded to fp32 (half the bytes; one all-gather,
+ *                           sums stay fp64).  Off by default and NOT within the 1e-10 criterion: 6e-8 relative rounding per
+ *                           entry and iteration ends at 1e-7 .. 1e-6 in the centrality vector, as the reference's own float
+ *                           runs do (parallel-final/output/single_double.txt:319: 1.2e-6) -- SURVEY 8(f) N4
  *   "lazy_normalisation"    1: multiply (and, with several ranks, exchange) the unnormalised vector, so that alpha and
  *                           beta come out of one reduction per iteration (one 2-double all-reduce) and one vector kernel;
  *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on

@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(_HERE, "liblzx.so")
 # the same code built with -DLZX_DEBUG_KNOBS: experiment knobs, test hooks, ablation switches (Makefile, `make debug`)
 DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
 # what the product library's lzx_set_option knows (include/lzx.h); any other option name selects the debug library
-PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "lazy_normalisation",
-                   "timing_marks_every")
+PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "exchange_fp32",
+                   "lazy_normalisation", "timing_marks_every")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)

@@ -100,6 +100,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "overlap_exchange")) c->overlap_opt = value;
     else if (!strcmp(name, "lazy_normalisation")) c->lazy_opt = value;
     else if (!strcmp(name, "sparse_exchange")) c->sparse_opt = value;
+    else if (!strcmp(name, "exchange_fp32")) c->xfp32_opt = value;
     else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
 #ifdef LZX_DEBUG_KNOBS
     // experiment knobs and test hooks: only in liblzx_dbg.so (make debug), which tests/ and tools/perf_probe.py load
@@ -356,6 +357,8 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             dst[i] = cs[i]->d_xbuf;
         }
         if (!overlap) {
+            if (c0->xfp32) LZX_TRY(lzx_comm_allgather_fp32(cs, src.data()));   // N4: the same prefix, rounded to fp32 on the wire
+            else
             LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs));   // only the prefix that has edges
             LZX_HIP(hipSetDevice(c0->device));
             LZX_TRY(mk.tick(CAT_COMM));
@@ -455,6 +458,8 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
                 src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
                 dst[i] = cs[i]->d_xbuf;
             }
+            if (c0->xfp32) LZX_TRY(lzx_comm_allgather_fp32(cs, src.data()));
+            else
             LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs));   // only the prefix that has edges
             LZX_HIP(hipSetDevice(c0->device));
             LZX_TRY(mk.tick(CAT_COMM));

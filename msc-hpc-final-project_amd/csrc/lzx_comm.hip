@@ -280,3 +280,34 @@ int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slic
     LZX_TRY(cross_barrier(cs, true));
     return LZX_OK;
 }
+
+// N4 (SURVEY 8 f): the per-iteration all-gather with the slices rounded to fp32 -- half the bytes on the wire.  Every
+// rank converts its slice, the floats are gathered, and every rank widens ALL slices (its own too: all ranks must
+// multiply the same vector) into the fp64 buffer the SpMV reads; sums stay fp64.  Main streams.
+int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc)
+{
+    lzx_ctx *c0 = cs[0];
+    const int world = c0->world;
+    const size_t cnt = c0->xs;
+    for (size_t i = 0; i < cs.size(); ++i) {
+        LZX_HIP(hipSetDevice(cs[i]->device));
+        LZX_TRY(lzx_launch_to_f32(cs[i], slice_loc[i], cs[i]->d_xf32_send, cnt));
+    }
+    if (c0->comm_kind == 2) {
+        LZX_NCCL(g_rccl.AllGather(c0->d_xf32_send, c0->d_xf32_full, cnt, ncclFloat, static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
+    } else {
+        if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
+        LZX_TRY(cross_barrier(cs));
+        for (int i = 0; i < world; ++i) {
+            LZX_HIP(hipSetDevice(cs[i]->device));
+            for (int p = 0; p < world; ++p)
+                LZX_HIP(hipMemcpyAsync(cs[i]->d_xf32_full + (size_t)p * cnt, cs[p]->d_xf32_send, cnt * sizeof(float), hipMemcpyDefault, cs[i]->stream));
+        }
+        LZX_TRY(cross_barrier(cs));
+    }
+    for (size_t i = 0; i < cs.size(); ++i) {
+        LZX_HIP(hipSetDevice(cs[i]->device));
+        LZX_TRY(lzx_launch_to_f64(cs[i], cs[i]->d_xf32_full, cs[i]->d_xbuf, (u64)world * cnt));
+    }
+    return LZX_OK;
+}

@@ -44,6 +44,9 @@ int lzx_graph_release(lzx_ctx *c)
     dev_free(c->d_sx_send_idx);
     dev_free(c->d_sx_sendbuf);
     dev_free(c->d_sx_map);
+    dev_free(c->d_xf32_send);
+    dev_free(c->d_xf32_full);
+    c->xfp32 = false;
     c->sparse = false;
     c->xc1 = 0;
     c->sx_recv_off.clear();
@@ -393,7 +396,8 @@ int lzx_graph_prepare(lzx_ctx *c)
     // of every slice, rounded so that chunk 0 ends on a column-band boundary, and must hold the LDS-staged hub entries.
     c->xs0 = c->xs;
     c->overlap = false;
-    if ((world > 1 || c->force_multi) && pb && c->overlap_opt != 0) {
+    c->xfp32 = (world > 1 || c->force_multi) && c->xfp32_opt > 0;   // N4: fp32 exchange uses the single all-gather
+    if ((world > 1 || c->force_multi) && pb && c->overlap_opt != 0 && !c->xfp32) {
         u32 x0 = round_up(std::max<u32>(c->xs / 8, (c->hub_real + world - 1) / world), LZX_PB_CB);
         if (x0 < c->xs) {
             c->xs0 = x0;
@@ -613,6 +617,7 @@ int lzx_graph_prepare(lzx_ctx *c)
         PREP_HIP(hipMemsetAsync(c->d_u[1], 0, sizeof(double) * c->ldq, st));
     }
     PREP(dev_alloc(&c->d_xbuf, c->xlen)); PREP(dev_alloc(&c->d_ybuf, c->iolen));
+    if (c->xfp32) { PREP(dev_alloc(&c->d_xf32_send, c->xs)); PREP(dev_alloc(&c->d_xf32_full, (u64)world * c->xs)); }
     PREP(dev_alloc(&c->d_io, n));
     PREP_HIP(hipMemsetAsync(c->d_v, 0, sizeof(double) * c->ldq, st));
     PREP_HIP(hipMemsetAsync(c->d_xbuf, 0, sizeof(double) * c->xlen, st));
@@ -893,7 +898,7 @@ extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
     o->exchange_chunk0 = c->overlap ? c->xs0 : 0;
     o->exchange_recv = 0;
     if (c->world > 1 || c->sparse) {
-        o->exchange_recv = (u64)(c->world - 1) * c->xs;
+        o->exchange_recv = (u64)(c->world - 1) * c->xs / (c->xfp32 ? 2 : 1);   // in doubles: fp32 entries count half
         if (c->sparse)
             o->exchange_recv = (u64)(c->world - 1) * c->xs0 + c->xc1 - (c->sx_recv_off[c->rank + 1] - c->sx_recv_off[c->rank]);
     }

@@ -111,6 +111,12 @@ struct lzx_ctx {
     u32 *d_sx_send_idx = nullptr;      // [sx_send_off[world]] local row index (>= xs0) of every packed entry, peer-major
     double *d_sx_sendbuf = nullptr;    // [sx_send_off[world]]
     u32 *d_sx_map = nullptr;           // [xc1] packed chunk-1 position -> position in the hand-over layout (p * n_loc_pad + l)
+    // N4 (SURVEY 8 f): the exchanged vector travels as fp32 (option exchange_fp32, off by default; single all-gather
+    // path only): every rank multiplies the SAME fp32-rounded vector, sums stay fp64
+    int64_t xfp32_opt = -1;
+    bool xfp32 = false;
+    float *d_xf32_send = nullptr;      // [xs] this rank's slice, rounded
+    float *d_xf32_full = nullptr;      // [world * xs] the gathered slices
     u64 n_active = 0;                  // vertices of degree > 0
     u32 rows_live = 0;                 // this rank's rows that have an edge (a prefix of its rows), rounded up to whole slices
     u64 xlen = 0;                      // world * xs + LZX_TAIL: length of the vector the SpMV gathers from
@@ -280,6 +286,10 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
 // own slice of the new vector) and the packed pieces land in the peers' d_xbuf behind chunk 0; on the exchange streams
 int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
 int lzx_launch_sx_pack(lzx_ctx *c, const double *slice_loc, hipStream_t st);
+// N4: all-gather of the slices as fp32 into every handle's d_xbuf (converted back to fp64 there), main streams
+int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
+int lzx_launch_to_f32(lzx_ctx *c, const double *in, float *out, u64 count);
+int lzx_launch_to_f64(lzx_ctx *c, const float *in, double *out, u64 count);
 // everything queued so far on every handle's `from` stream happens before what is queued next on every `to` stream
 int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream2);
 void lzx_comm_release(lzx_ctx *c);

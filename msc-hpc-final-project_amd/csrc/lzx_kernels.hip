@@ -504,6 +504,17 @@ __global__ void k_sx_pack(const double *slice, const u32 *idx, u32 count, double
     if (i < count) out[i] = slice[idx[i]];
 }
 
+__global__ void k_to_f32(const double *in, float *out, u64 count)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (float)in[i];
+}
+__global__ void k_to_f64(const float *in, double *out, u64 count)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (double)in[i];
+}
+
 __global__ void k_permute_out(const double *full, const u32 *gidx, double *io, u64 n)
 {
     const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,6 +705,19 @@ int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io)
     if (c->n == 0) return LZX_OK;
     const u32 g = (u32)((c->n + 255) / 256);
     hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, c->stream, full, c->d_gidx_of_old, io, c->n);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_to_f32(lzx_ctx *c, const double *in, float *out, u64 count)
+{
+    if (count) hipLaunchKernelGGL(k_to_f32, dim3((u32)((count + 255) / 256)), dim3(256), 0, c->stream, in, out, count);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+int lzx_launch_to_f64(lzx_ctx *c, const float *in, double *out, u64 count)
+{
+    if (count) hipLaunchKernelGGL(k_to_f64, dim3((u32)((count + 255) / 256)), dim3(256), 0, c->stream, in, out, count);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }
