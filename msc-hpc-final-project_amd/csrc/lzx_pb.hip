@@ -659,6 +659,9 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
 }
 
 
+#ifdef LZX_DEBUG_KNOBS
+// ==== round-2 experiments (DESIGN.md section 3.1 g): compiled into liblzx_dbg.so only, selected by the debug knob
+// pb_persistent (1 static schedule, 2 tickets); none was faster than the per-unit kernels above, which both libraries run.
 // One reduced step, lean form (the scatter pass turned out to be bound by its instruction stream, not by memory:
 // with stores, LDS look-ups and the carry all switched off it still took 0.27 of its 0.31 ms, profiles/README.md).
 // Same format, same value order and the same sums as k_pb_scatter's step body, in about half the instructions:
@@ -709,7 +712,7 @@ __device__ __forceinline__ void pbr_step(const uint4 &c, u32 pos, const double *
     }
 }
 
-// ---- persistent forms of the two passes (default) ---------------------------------------------------------------
+// ---- persistent forms of the two passes (experiments of round 2; debug library only) ---------------------------
 // Both passes above start every work unit cold: a unit record, then the tables it points to, then the first loads --
 // three dependent memory round trips (plus, in the scatter pass, the 128 KiB band) before a workgroup streams, with one
 // (scatter) or two (gather) workgroups per CU to hide them behind.  unit_bench (tools/unit_bench.hip) shows the inner
@@ -1154,6 +1157,8 @@ k_pb_gather2(const uint4 *items2, const u32 *wg_begin, const uint16_t *lslot, co
     }
 }
 
+#endif  // LZX_DEBUG_KNOBS
+
 template <typename T>
 int pb_alloc(T **p, u64 count)
 {
@@ -1306,6 +1311,7 @@ int pb_units(lzx_ctx *c, hipStream_t st, const std::vector<u32> &sstart, const s
     return LZX_OK;
 }
 
+#ifdef LZX_DEBUG_KNOBS
 // Static scatter schedule: the scatter order (band by band: a band's steps, then its quads) is cut into `groups`
 // stretches of equal cost -- bytes read + written: per step its 1 KiB of codes + 8 B per piece, per quad 12 B + 32 B --
 // one per workgroup; a stretch is stored as segments {band, steps, quads}, one per band it touches.  Two schedules:
@@ -1401,6 +1407,8 @@ int pb_segments(lzx_ctx *c, hipStream_t st, const std::vector<u32> &sstart, cons
     LZX_HIP(hipStreamSynchronize(st));
     return LZX_OK;
 }
+
+#endif
 
 int pb_download(hipStream_t st, const u32 *d, size_t count, std::vector<u32> &h)
 {
@@ -1641,7 +1649,9 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     }
     ar.drop(d_plcol); ar.drop(d_qcband);
     LZX_TRY(pb_units(c, st, sstart, qstart, nb, unit_cap));
-    LZX_TRY(pb_segments(c, st, sstart, qstart, nb, nsteps));
+#ifdef LZX_DEBUG_KNOBS
+    if (c->pb_persist_opt == 1) LZX_TRY(pb_segments(c, st, sstart, qstart, nb, nsteps));   // static scatter schedule (experiment)
+#endif
     LZX_HIP(hipGetLastError());
 
     // 6. conflict-free LDS slots for the gather pass
@@ -1710,6 +1720,8 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     // 16 wavefronts per CU (their private y tiles fill the LDS): two workgroups of eight, or four of four
     c->pb_gather_block = c->pb_gwaves_opt == 4 ? 256u : 512u;
     c->pb_gather_grid = std::min<u32>((u32)c->cu_count * (1024u / c->pb_gather_block), std::max(1u, c->pb_n_items));
+#ifdef LZX_DEBUG_KNOBS
+    if (c->pb_persist_opt > 0)
     {   // records of the persistent gather pass: everything an item needs in one place.  Items are dealt to the
         // workgroups here, longest first, each to the workgroup with the least work so far (cost = bytes streamed + a
         // fixed share for the fold), and laid out workgroup by workgroup.
@@ -1755,6 +1767,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         for (u32 &b : c->pb_qbase) b = 0;
         LZX_HIP(hipStreamSynchronize(st));
     }
+#endif
     {   // split rows (the first n_long64 local rows) that are also rows of a multi-item band
         std::vector<uint8_t> flag((size_t)c->n_long64 + 1, 0);
         for (size_t i = 0; i < multi.size(); i += 4)
@@ -1819,19 +1832,22 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
 #endif
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    // default: one workgroup per unit / static item lists (k_pb_scatter, k_pb_gather).  The persistent forms below are
-    // kept for the record of DESIGN.md section 3 (debug knob pb_persistent: 1 static schedule, 2 tickets): none was faster.
+    // both libraries run one workgroup per unit / static item lists (k_pb_scatter, k_pb_gather); the persistent forms are
+    // round-2 experiments kept in the debug library (knob pb_persistent: 1 static schedule, 2 tickets): none was faster
+#ifdef LZX_DEBUG_KNOBS
     const bool persistent = c->pb_persist_opt > 0 && !ablate;
     const size_t lds1p = lds1 + 16;
     auto kern2 = c->pb_cb == 8192 ? k_pb_scatter2<8192> : k_pb_scatter2<LZX_PB_CB>;
     if (c->pb_units && persistent)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1p));
     auto kern3 = c->pb_cb == 8192 ? k_pb_scatter3<8192> : k_pb_scatter3<LZX_PB_CB>;
-    const bool fixed = persistent && c->pb_persist_opt != 2;   // 2 = the ticket-driven form (debug knob)
+    const bool fixed = persistent && c->pb_persist_opt != 2;   // 2 = the ticket-driven form
     if (c->pb_units && fixed)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1p));
+#endif
     auto scatter = [&](u32 u0, u32 u1) {
         if (u1 <= u0) return;
+#ifdef LZX_DEBUG_KNOBS
         if (fixed) {
             // schedule 0 = the bands of chunk 0 (units [0, pb_units0)), schedule 1 = the rest; a call for all units runs both
             for (int part = 0; part < 2; ++part) {
@@ -1853,6 +1869,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
             c->pb_qbase[q] += n + grid;
             return;
         }
+#endif
         hipLaunchKernelGGL(kern, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
                            c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val, ablate);
     };
@@ -1877,6 +1894,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (c->phase_mask_opt & 8) {
         // experiment: scatter pass alone
+#ifdef LZX_DEBUG_KNOBS
     } else if (persistent) {
         const u32 block = c->pb_gather_block;
         const size_t lds2p = ((size_t)(block / 64) * (LZX_PB_RB + 8) + block / 64) * sizeof(double) + 16;
@@ -1885,6 +1903,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         hipLaunchKernelGGL(gk, dim3(c->pb_gather_grid), dim3(block), lds2p, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_items2), c->d_pb_wg_begin, c->d_pb_lrow, c->d_pb_val, v, q_loc,
                            c->d_pb_part, partials, c->d_pb_stamps ? c->d_pb_stamps + 8192 : nullptr);
+#endif
     } else
     hipLaunchKernelGGL(k_pb_gather, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_lrow,
