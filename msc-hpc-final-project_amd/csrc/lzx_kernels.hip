@@ -59,6 +59,7 @@ struct SpmvArgs {
     u32 world;
     u32 xs0;       // slice stride of chunk 0 of the exchange layout (the staged hub entries all live there)
     u32 n_zero;    // blocked mode: v[0 .. n_zero) (the split rows) starts at 0; the blocked passes and k_pb_finish add to it
+    u32 deep;      // blocked mode: slices pipelined four deep instead of two
 };
 
 // Column code c: c < hub -> value staged in LDS slot c; otherwise x[c - hub].
@@ -235,9 +236,8 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
             const u32 di = w0 + (base + (lane < cnt ? lane : 0)) * waves;
             const u64 d_off = a.slice_off[di];
             const u32 d_st = a.slice_w[di] >> 2;   // packets per lane
-            // PF packets of the next slice are in flight while this one is summed: 4 in plain mode; 8 in blocked mode,
-            // whose staged-only slices are 6.5 packets wide on average (C3) and whose kernel is bound by memory round trips
-            constexpr int PF = HUB == 2 ? 8 : 4;
+            // PF packets of a slice are fetched ahead of its summation (8 instead of 4 changed nothing in blocked mode)
+            constexpr int PF = 4;
             auto issue = [&](u32 j, uint4 (&f)[PF], double &qrow) {
                 const PK *p = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, j)) + lane;
                 const u32 st = lane_u32(d_st, j);
@@ -286,6 +286,31 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
                 a.v[a.row0 + (w0 + (base + j) * waves) * 64 + lane] = acc;
                 dot += acc * qrow;
             };
+            if (HUB == 2 && a.deep) {
+                // blocked mode: the staged-only slices are short (a few hundred clocks of work each) and the kernel waits on
+                // memory round trips, not bandwidth (SQ_WAIT_ANY 70 %): the packets of the next THREE slices are in flight
+                // while one is summed -- four register sets used in rotation, every load from a clamped, valid address
+                uint4 f0[PF], f1[PF], f2[PF], f3[PF];
+                double q0, q1, q2, q3;
+                const u32 lastj = cnt - 1;
+                auto at = [&](u32 j) { return j < cnt ? j : lastj; };
+                issue(0, f0, q0);
+                issue(at(1), f1, q1);
+                issue(at(2), f2, q2);
+                for (u32 j = 0; j < cnt; j += 4) {
+                    issue(at(j + 3), f3, q3);
+                    consume(j, f0, q0);
+                    if (j + 1 >= cnt) break;
+                    issue(at(j + 4), f0, q0);
+                    consume(j + 1, f1, q1);
+                    if (j + 2 >= cnt) break;
+                    issue(at(j + 5), f1, q1);
+                    consume(j + 2, f2, q2);
+                    if (j + 3 >= cnt) break;
+                    issue(at(j + 6), f2, q2);
+                    consume(j + 3, f3, q3);
+                }
+            } else {
             uint4 fa[PF], fb[PF];
             double qa, qb;
             issue(0, fa, qa);
@@ -295,6 +320,7 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
                 if (j + 1 >= cnt) break;
                 issue(j + 2 < cnt ? j + 2 : j + 1, fa, qa);
                 consume(j + 1, fb, qb);
+            }
             }
         }
     }
@@ -578,6 +604,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.world = (u32)c->world;
     a.xs0 = c->xs0;
     a.n_zero = c->pb ? c->n_long64 : 0;
+    a.deep = c->deep_opt > 0 ? 1u : 0u;   // debug knob spmv_deep: no gain measured (DESIGN.md 3.1 g), off
     const bool nt = c->nt_opt > 0;
     // Blocked mode, option "side_stream": the staged-columns kernel and the scatter passes are independent (both only
     // read x), so the former can run on a side stream, its drain overlapping the scatter's ramp-up; the gather pass,
