@@ -189,5 +189,5 @@ def test_bench_rehearses_the_multi_gpu_flow():
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     tune = j["config"]["exchange_tuning_ms_per_iter"]
-    assert set(tune) == {"single", "overlapped"} and min(tune.values()) > 0
+    assert {"single", "overlapped"} <= set(tune) and min(tune["single"], tune["overlapped"]) > 0
     assert j["value"] > 0 and j["config"]["lanczos_coefficients_finite"]
