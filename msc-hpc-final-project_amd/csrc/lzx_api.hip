@@ -119,6 +119,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_stamps")) c->pb_stamps_opt = value;
     else if (!strcmp(name, "pb_order")) c->pb_order_opt = value;
     else if (!strcmp(name, "spmv_deep")) c->deep_opt = value;
+    else if (!strcmp(name, "tie_sort")) c->tie_sort_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;

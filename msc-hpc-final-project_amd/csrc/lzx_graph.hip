@@ -88,6 +88,46 @@ __global__ void k_degrees(const u64 *row_ptr, u32 *deg, u32 *ids, u64 n)
     }
 }
 
+// Blocked mode: rows of EQUAL degree are ordered by their number of staged (top-`hub`) columns, so that the 64 rows of a
+// staged-only slice are about equally wide (degree alone leaves that count Poisson-scattered: a low-degree slice was
+// two to three times as wide as its mean row).  The staged set itself is fixed by the first ranking.
+__global__ void k_rank_of_old(const u32 *sorted_ids, u32 *rank_of_old, u64 n)
+{
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) rank_of_old[sorted_ids[r]] = (u32)r;
+}
+
+// one wavefront per ranked vertex (strided over the grid): key = degree << 32 | staged count; the staged vertices
+// themselves keep their order (low word counts down from 2^32 - 1, above any count)
+__global__ void __launch_bounds__(64)
+k_staged_key(const u64 *row_ptr, const u32 *col_idx, const u32 *sorted_ids, const u32 *sorted_deg, const u32 *rank_of_old,
+             u64 n_active, u64 n, u32 hub, int count_major, u64 *key)
+{
+    const u32 lane = threadIdx.x;
+    for (u64 r = blockIdx.x; r < n; r += gridDim.x) {
+        const u32 d = sorted_deg[r];
+        u32 low = 0;
+        if (r < hub) {
+            if (lane == 0) key[r] = count_major ? ~(u64)r : ((u64)d << 32) | (0xffffffffu - (u32)r);
+            continue;
+        } else if (r < n_active) {
+            const u64 base = row_ptr[sorted_ids[r]];
+            u32 cnt = 0;
+            for (u32 k = lane; k < d; k += 64) cnt += rank_of_old[col_idx[base + k]] < hub ? 1u : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            low = cnt;
+        }
+        if (lane == 0) key[r] = count_major ? ((u64)low << 32) | d : ((u64)d << 32) | low;
+    }
+}
+
+__global__ void k_degree_of(const u32 *deg_of_old, const u32 *sorted_ids, u32 *sorted_deg, u64 n)
+{
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) sorted_deg[r] = deg_of_old[sorted_ids[r]];
+}
+
 // degree rank r -> position in the exchange layout and column code
 __global__ void k_rank_maps(const u32 *sorted_ids, u32 *gidx_of_old, u32 *code_of_old, u64 n,
                             u32 world, u32 n_loc_pad, u32 xs, u32 xs0, u32 hub)
@@ -416,6 +456,33 @@ int lzx_graph_prepare(lzx_ctx *c)
     if (!pb) {
         c->xs0 = c->xs;
         c->overlap = false;
+    }
+    if (pb && c->n_active > c->hub_real && c->tie_sort_opt != 0) {
+        // ---- 1a. ties of the degree ranking broken by the staged-column count (see k_staged_key); d_code is free until
+        //          k_rank_maps fills it and serves as the rank-of-vertex scratch, d_ids as the second value buffer
+        u64 *d_key = nullptr, *d_skey = nullptr;
+        rc = dev_alloc(&d_key, n);
+        if (rc == LZX_OK) rc = dev_alloc(&d_skey, n);
+        if (rc != LZX_OK) { dev_free(d_key); dev_free(d_skey); cleanup(); return rc; }
+        hipLaunchKernelGGL(k_rank_of_old, dim3(gb), dim3(256), 0, st, d_sids, d_code, n);
+        hipLaunchKernelGGL(k_staged_key, dim3((u32)std::min<u64>(n, 1u << 20)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_sids,
+                           d_sdeg, d_code, c->n_active, n, c->hub_real, c->tie_sort_opt == 2 ? 1 : 0, d_key);
+        size_t tb = 0;
+        hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, d_key, d_skey, d_sids, d_ids, (u64)n, 0, 64, st);
+        if (e == hipSuccess && tb > tmp_bytes) {
+            (void)hipFree(d_tmp);
+            d_tmp = nullptr;
+            e = hipMalloc(&d_tmp, tb);
+            if (e == hipSuccess) tmp_bytes = tb;
+        }
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tb, d_key, d_skey, d_sids, d_ids, (u64)n, 0, 64, st);
+        if (e == hipSuccess) {
+            e = hipMemcpyAsync(d_sids, d_ids, sizeof(u32) * n, hipMemcpyDeviceToDevice, st);
+            hipLaunchKernelGGL(k_degree_of, dim3(gb), dim3(256), 0, st, d_deg, d_sids, d_sdeg, n);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        dev_free(d_key); dev_free(d_skey);
+        PREP_HIP(e);
     }
     const u32 sentinel = pb ? c->hub_real : c->hub + (u32)((u64)world * c->xs);
     hipLaunchKernelGGL(k_rank_maps, dim3(gb), dim3(256), 0, st, d_sids, c->d_gidx_of_old, d_code, n,

@@ -192,6 +192,7 @@ struct lzx_ctx {
     u32 pb_qbase[4] = {0, 0, 0, 0};    // value each counter will have when its next launch starts
     unsigned long long *d_pb_stamps = nullptr;   // [3][4096] debug library, option pb_stamps: per-workgroup start / end ticks
     int64_t pb_stamps_opt = -1;
+    int64_t tie_sort_opt = -1;         // blocked mode: ties of the degree ranking broken by staged-column count (debug knob; 0 = by id)
     int64_t deep_opt = -1;             // staged-columns kernel: 1 = four slices in flight instead of two (debug knob; no gain)
     int64_t pb_order_opt = -1;         // kernel order of the blocked SpMV (debug knob): -1/1 scatter, staged columns, gather; 0 staged columns first
     int64_t pb_gwaves_opt = -1;        // wavefronts per gather workgroup (debug knob): 8 (default) or 4

@@ -1458,8 +1458,18 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     if (reduce) {
         u32 l = 0;
         while (l < c->n_loc_real) {
+            // replicas for the band's heaviest row (rows are ranked by degree or by staged-column count: the blocked
+            // count falls only roughly along the order)
             u32 rep = 1;
-            while (rep < 64 && (u64)rep * 2 * nb < h_nh[l]) rep <<= 1;
+            for (;;) {
+                const u32 e = (u32)std::min<u64>((u64)l + LZX_PB_RB / rep, c->n_loc_real);
+                u32 heaviest = 0;
+                for (u32 j = l; j < e; ++j) heaviest = std::max(heaviest, h_nh[j]);
+                u32 need = rep;
+                while (need < 64 && (u64)need * 2 * nb < heaviest) need <<= 1;
+                if (need == rep) break;
+                rep = need;
+            }
             l = (u32)std::min<u64>((u64)l + LZX_PB_RB / rep, c->n_loc_real);
             row0.push_back(l);
         }

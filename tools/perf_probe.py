@@ -43,6 +43,8 @@ if __name__ == "__main__":
     if "diag2" in sets:
         opts = [dict(pb_stamps=1), dict(pb_stamps=1, pb_gather_waves=4), dict(pb_stamps=1, hub_entries=2), dict(pb_stamps=1, hub_entries=1024),
                 dict(pb_stamps=1, hub_entries=4096), dict(pb_stamps=1, hub_entries=8192), dict(pb_stamps=1, hub_entries=2, pb_gather_waves=4)]
+    if "tie" in sets:
+        opts = [dict(tie_sort=1), dict(tie_sort=2), dict(tie_sort=0), dict(tie_sort=1), dict(tie_sort=2), dict(tie_sort=0)]
     if "deep" in sets:
         opts = [dict(spmv_deep=1), dict(spmv_deep=0), dict(spmv_deep=1), dict(spmv_deep=0)]
     if "st2" in sets:
