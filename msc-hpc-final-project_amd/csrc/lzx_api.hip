@@ -120,6 +120,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_order")) c->pb_order_opt = value;
     else if (!strcmp(name, "spmv_deep")) c->deep_opt = value;
     else if (!strcmp(name, "tie_sort")) c->tie_sort_opt = value;
+    else if (!strcmp(name, "pb_group")) c->pb_group_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
@@ -824,27 +825,34 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
         // one more SpMV with marks between its kernels: hub/body, split-row finish, scatter, gather (+finish)
         for (auto &ev : c->trace_ev)
             if (!ev) LZX_HIP(hipEventCreate(&ev));
-        c->trace = true;
-        for (auto &ev : c->trace_ev) LZX_HIP(hipEventRecord(ev, c->stream));
-        int rc = lzx_launch_spmv(c, l);
-        c->trace = false;
-        LZX_TRY(rc);
-        LZX_HIP(hipStreamSynchronize(c->stream));
         float t[4] = {0, 0, 0, 0};
         const bool scatter_first = c->pb && c->pb_order_opt != 0 && !(c->side_opt > 0);
-        (void)hipEventElapsedTime(&t[0], c->trace_ev[0], c->trace_ev[1]);
-        if (scatter_first) {
-            (void)hipEventElapsedTime(&t[2], c->trace_ev[2], c->trace_ev[3]);
-            (void)hipEventElapsedTime(&t[3], c->trace_ev[5], c->trace_ev[4]);
-        } else {
-            (void)hipEventElapsedTime(&t[1], c->trace_ev[1], c->trace_ev[2]);
-            if (c->pb) {
-                (void)hipEventElapsedTime(&t[2], c->trace_ev[2], c->trace_ev[3]);
-                (void)hipEventElapsedTime(&t[3], c->trace_ev[3], c->trace_ev[4]);
+        constexpr int TR = 8;   // traced SpMVs, averaged (the marks cost a few microseconds each)
+        for (int rep = 0; rep < TR; ++rep) {
+            c->trace = true;
+            for (auto &ev : c->trace_ev) LZX_HIP(hipEventRecord(ev, c->stream));
+            int rc = lzx_launch_spmv(c, l);
+            c->trace = false;
+            LZX_TRY(rc);
+            LZX_HIP(hipStreamSynchronize(c->stream));
+            float d[4] = {0, 0, 0, 0};
+            (void)hipEventElapsedTime(&d[0], c->trace_ev[0], c->trace_ev[1]);
+            if (scatter_first) {
+                (void)hipEventElapsedTime(&d[2], c->trace_ev[2], c->trace_ev[3]);
+                (void)hipEventElapsedTime(&d[3], c->trace_ev[5], c->trace_ev[4]);
+            } else {
+                (void)hipEventElapsedTime(&d[1], c->trace_ev[1], c->trace_ev[2]);
+                if (c->pb) {
+                    (void)hipEventElapsedTime(&d[2], c->trace_ev[2], c->trace_ev[3]);
+                    (void)hipEventElapsedTime(&d[3], c->trace_ev[3], c->trace_ev[4]);
+                }
             }
+            for (int q = 0; q < 4; ++q) t[q] += d[q] / TR;
         }
-        fprintf(stderr, "[lzx trace] k_spmv %.4f ms  long_finish %.4f ms  pb_scatter %.4f ms  pb_gather(+finish) %.4f ms\n",
-                t[0], t[1], t[2], t[3]);
+        fprintf(stderr, "[lzx trace] val %p code %p lslot %p sell %p v %p xbuf %p ybuf %p\n", (void *)c->d_pb_val, (void *)c->d_pbr_code,
+                (void *)c->d_pb_lrow, (void *)c->d_sell_cols, (void *)c->d_v, (void *)c->d_xbuf, (void *)c->d_ybuf);
+        fprintf(stderr, "[lzx trace] k_spmv %.4f ms  long_finish %.4f ms  pb_scatter %.4f ms  pb_gather(+finish) %.4f ms  (mean of %d)\n",
+                t[0], t[1], t[2], t[3], TR);
         if (c->d_pb_stamps) {
             // per-workgroup time lines of the persistent passes (100 MHz ticks): when did workgroups start and end
             std::vector<unsigned long long> h(3 * 4096);

@@ -57,6 +57,8 @@ static constexpr u32 LZX_PB_RB = 1024;
 static constexpr u32 LZX_PB_TARGET = 32768;   // upper limit of the values per gather item (one wavefront each)
 static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
+static constexpr u32 LZX_PB_GROUP = 16384;    // a row band of at most this many values is gathered by one wavefront (k_pb_gather)
+static constexpr u32 LZX_PB_ITEM_GROUP = 0xfffffffeu, LZX_PB_ITEM_NONE = 0xfffffffdu;   // item.w markers (0xffffffff: adds into v)
 // entries, padded entries and values of one rank's blocked tables are indexed with 32 bits (a margin is left for the
 // kernels' look-ahead)
 static constexpr u64 LZX_PB_SLOT_LIMIT = (1ull << 32) - (1ull << 24);
@@ -177,6 +179,7 @@ struct lzx_ctx {
     u32 *d_pb_unit = nullptr;          // [pb_units][5] band, first / last step (reduced part), first / last quad (plain part)
     u32 *d_pb_row0 = nullptr;          // [pb_nr + 1] first local row of each row band
     u32 *d_pb_rep = nullptr;           // [pb_nr] LDS slots per row in that band's y tile
+    u32 *d_pb_beg = nullptr;           // [pb_nr + 1] first value of each row band in gather order
     u32 *d_pb_items = nullptr;         // [pb_n_items][4] row band, begin, end (gather order), slot or ~0
     u32 *d_pb_multi = nullptr;         // [pb_n_multi][4] row, first slot, items, slot stride: rows of bands cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows
@@ -195,6 +198,7 @@ struct lzx_ctx {
     int64_t tie_sort_opt = -1;         // blocked mode: ties of the degree ranking broken by staged-column count (debug knob; 0 = by id)
     int64_t deep_opt = -1;             // staged-columns kernel: 1 = four slices in flight instead of two (debug knob; no gain)
     int64_t pb_order_opt = -1;         // kernel order of the blocked SpMV (debug knob): -1/1 scatter, staged columns, gather; 0 staged columns first
+    int64_t pb_group_opt = -1;         // values up to which a row band is gathered by ONE wavefront, eight such bands per workgroup item (debug knob; 0 = off)
     int64_t pb_gwaves_opt = -1;        // wavefronts per gather workgroup (debug knob): 8 (default) or 4
     u32 pb_gather_block = 512;
     int64_t pb_persist_opt = -1;       // persistent passes: -1/1 on, 0 = one workgroup per unit / static item lists

@@ -505,8 +505,9 @@ __device__ __forceinline__ double wave_sum_pb(double v)
 // consecutive KiB at a time -- a few hundred sequential streams chip-wide instead of four thousand), each adding into
 // its own y tile; the tiles are folded in wavefront order.
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
-k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *band_rep, const uint16_t *lslot,
-            const double *val, double *v, const double *__restrict__ q_loc, double *part, double *partials)
+k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *band_rep, const u32 *band_beg,
+            const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
+            double *partials)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
@@ -518,6 +519,92 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     double dot = 0.0;
     for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
         const uint4 item = items[it];
+        if (item.w == LZX_PB_ITEM_NONE) continue;   // filler of the balanced schedule
+        if (item.w == LZX_PB_ITEM_GROUP) {
+            // a group of up to eight SMALL consecutive bands, one per wavefront: each wavefront streams its own band into
+            // its own tile and folds it itself -- no workgroup barrier, no cross-wavefront fold, eight bands' round trips
+            // in flight per workgroup (the low-degree end of the row order is thousands of bands of a few thousand values)
+            __syncthreads();                 // the previous item's fold (it reads every wavefront's tile) is done
+            if (wv < item.y) {
+                const u32 R = item.x + wv;
+                const u32 row0 = band_row0[R], rows = band_row0[R + 1] - row0, rep = band_rep[R];
+                const u32 beg = band_beg[R], end = band_beg[R + 1];
+                const u32 slots = rows * rep;
+                for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
+                __builtin_amdgcn_wave_barrier();
+                const u32 blocks = (end - beg) / 128u;
+                u32 kb = 0;
+                for (; kb + 8 <= blocks; kb += 8) {
+                    double2 av[8];
+                    u32 sv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const u32 p = beg + (kb + u) * 128u + lane * 2;
+                        av[u] = *reinterpret_cast<const double2 *>(val + p);
+                        sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                        atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                    }
+                }
+                {   // up to seven more blocks and the band's tail (< 128 values): all fetched before the first add
+                    double2 av[7];
+                    u32 sv[7];
+                    double tv[2] = {0.0, 0.0};
+                    u32 ts[2] = {LZX_PB_RB, LZX_PB_RB};
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        if (kb + u < blocks) {           // wave-uniform
+                            const u32 p = beg + (kb + u) * 128u + lane * 2;
+                            av[u] = *reinterpret_cast<const double2 *>(val + p);
+                            sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const u32 i = beg + blocks * 128u + lane + u * 64;
+                        if (i < end) {
+                            tv[u] = val[i];
+                            ts[u] = lslot[i];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        if (kb + u < blocks) {
+                            atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                            atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                        }
+                    }
+                    atomicAdd(&ytile[ts[0]], tv[0]);
+                    __builtin_amdgcn_wave_barrier();   // the tail goes 64 consecutive values per instruction, in order
+                    atomicAdd(&ytile[ts[1]], tv[1]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // fold: replicas in order; four rows per lane at a time, loads before stores
+                for (u32 j0 = lane; j0 < rows; j0 += 256) {
+                    double vv[4], qq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 j = j0 + u * 64;
+                        vv[u] = j < rows ? v[row0 + j] : 0.0;
+                        qq[u] = j < rows ? q_loc[row0 + j] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 j = j0 + u * 64;
+                        if (j < rows) {
+                            double y = 0.0;
+                            for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                            v[row0 + j] = vv[u] + y;
+                            dot += y * qq[u];
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         const u32 R = item.x, beg = item.y, end = item.z;
         const u32 row0 = band_row0[R], rows = band_row0[R + 1] - row0;
         if (rows == 1) {
@@ -1183,6 +1270,7 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_unit);
     pb_free(c->d_pb_row0);
     pb_free(c->d_pb_rep);
+    pb_free(c->d_pb_beg);
     pb_free(c->d_pb_items);
     pb_free(c->d_pb_items2);
     pb_free(c->d_pb_wg_begin);
@@ -1730,6 +1818,78 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     // 16 wavefronts per CU (their private y tiles fill the LDS): two workgroups of eight, or four of four
     c->pb_gather_block = c->pb_gwaves_opt == 4 ? 256u : 512u;
     c->pb_gather_grid = std::min<u32>((u32)c->cu_count * (1024u / c->pb_gather_block), std::max(1u, c->pb_n_items));
+    LZX_TRY(pb_alloc(&c->d_pb_beg, (u64)nr + 1));
+    LZX_HIP(hipMemcpyAsync(c->d_pb_beg, rstart.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
+    const u32 group_cap = c->pb_group_opt >= 0 ? (u32)c->pb_group_opt : LZX_PB_GROUP;
+    if (group_cap > 0 && c->pb_gather_block == 512u && c->pb_persist_opt <= 0) {
+        // Small bands (the low-degree end of the row order: thousands of bands of a few thousand values, each of which
+        // cost a workgroup three dependent round trips and two barriers) are gathered by ONE wavefront each, up to eight
+        // consecutive ones per item.  Then the items are dealt to the workgroups longest first, each to the workgroup with
+        // the least work so far, and stored round by round, so that the kernel's strided loop
+        // (item = workgroup + round * grid) walks that schedule: which workgroup adds which share of alpha stays fixed.
+        std::vector<u32> out;
+        auto small = [&](size_t i) {
+            const u32 R = items[4 * i];
+            return items[4 * i + 3] == 0xffffffffu && row0[R + 1] - row0[R] > 1 && items[4 * i + 2] - items[4 * i + 1] <= group_cap;
+        };
+        std::vector<u64> cost;
+        const size_t ni = items.size() / 4;
+        // as many bands per group as still leave every workgroup an item or two: on a small graph (a few hundred bands)
+        // a band per workgroup is the faster form -- the pass is a handful of round trips long either way
+        size_t n_small = 0;
+        for (size_t i = 0; i < ni; ++i) n_small += small(i) ? 1 : 0;
+        const size_t per_group = std::min<size_t>(8, n_small / std::max<u32>(1u, c->pb_gather_grid));
+        for (size_t i = 0; i < ni;) {
+            if (per_group < 2 || !small(i)) {
+                const u32 R = items[4 * i];
+                out.insert(out.end(), items.begin() + 4 * i, items.begin() + 4 * i + 4);
+                cost.push_back(10ull * (items[4 * i + 2] - items[4 * i + 1]) + 24ull * (row0[R + 1] - row0[R]) + 40000ull);
+                ++i;
+                continue;
+            }
+            size_t j = i;
+            u64 vals = 0, rows = 0, widest = 0;
+            while (j < ni && j - i < per_group && small(j) && items[4 * j] == items[4 * i] + (u32)(j - i)) {
+                const u32 R = items[4 * j];
+                vals += items[4 * j + 2] - items[4 * j + 1];
+                widest = std::max<u64>(widest, items[4 * j + 2] - items[4 * j + 1]);
+                rows += row0[R + 1] - row0[R];
+                ++j;
+            }
+            out.push_back(items[4 * i]); out.push_back((u32)(j - i)); out.push_back((u32)vals); out.push_back(LZX_PB_ITEM_GROUP);
+            // a group lasts as long as its widest band's wavefront: eight serial batches per Ki values
+            cost.push_back(std::max<u64>(10ull * vals + 24ull * rows, 80ull * widest) + 40000ull);
+            i = j;
+        }
+        const u32 G = c->pb_gather_grid;
+        const size_t no = cost.size();
+        std::vector<u32> order(no);
+        for (size_t i = 0; i < no; ++i) order[i] = (u32)i;
+        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b2) { return cost[a] > cost[b2]; });
+        std::vector<std::vector<u32>> lists(G);
+        std::priority_queue<std::pair<u64, u32>, std::vector<std::pair<u64, u32>>, std::greater<std::pair<u64, u32>>> heap;
+        for (u32 w = 0; w < G; ++w) heap.push({0ull, w});
+        size_t rounds = 0;
+        for (u32 i : order) {
+            auto [load, w] = heap.top();
+            heap.pop();
+            lists[w].push_back(i);
+            rounds = std::max(rounds, lists[w].size());
+            heap.push({load + cost[i], w});
+        }
+        items.assign(rounds * G * 4, 0u);
+        for (size_t r = 0; r < rounds; ++r)
+            for (u32 w = 0; w < G; ++w) {
+                u32 *o = &items[4 * (r * G + w)];
+                if (r < lists[w].size()) {
+                    const u32 *it = &out[4 * (size_t)lists[w][r]];
+                    o[0] = it[0]; o[1] = it[1]; o[2] = it[2]; o[3] = it[3];
+                } else {
+                    o[3] = LZX_PB_ITEM_NONE;
+                }
+            }
+        c->pb_n_items = (u32)(items.size() / 4);
+    }
 #ifdef LZX_DEBUG_KNOBS
     if (c->pb_persist_opt > 0)
     {   // records of the persistent gather pass: everything an item needs in one place.  Items are dealt to the
@@ -1916,7 +2076,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
 #endif
     } else
     hipLaunchKernelGGL(k_pb_gather, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
-                       reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_lrow,
+                       reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,
                        c->d_pb_val, v, q_loc, c->d_pb_part, partials);
     if (c->pb_finish_grid)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,

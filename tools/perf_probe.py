@@ -45,6 +45,10 @@ if __name__ == "__main__":
                 dict(pb_stamps=1, hub_entries=4096), dict(pb_stamps=1, hub_entries=8192), dict(pb_stamps=1, hub_entries=2, pb_gather_waves=4)]
     if "tie" in sets:
         opts = [dict(tie_sort=1), dict(tie_sort=2), dict(tie_sort=0), dict(tie_sort=1), dict(tie_sort=2), dict(tie_sort=0)]
+    if "grp" in sets:
+        opts = [dict(pb_group=16384), dict(pb_group=0), dict(pb_group=8192), dict(pb_group=12288), dict(pb_group=20480), dict(pb_group=24576), dict(pb_group=16384), dict(pb_group=0)]
+    if "grp2" in sets:
+        opts = [dict(pb_group=16384), dict(pb_group=0)] * 4
     if "deep" in sets:
         opts = [dict(spmv_deep=1), dict(spmv_deep=0), dict(spmv_deep=1), dict(spmv_deep=0)]
     if "st2" in sets:
@@ -96,5 +100,18 @@ if __name__ == "__main__":
     if "phase" in sets:
         opts = [dict(phase_mask=1), dict(phase_mask=2), dict(phase_mask=1, hub_entries=0), dict(phase_mask=2, hub_entries=0),
                 dict(long_row=256), dict(long_row=4096), dict(long_row=65536)]
+    if "fresh" in sets:
+        # every configuration in its own process: engines created one after another in one process see different
+        # physical memory layouts (a "fast" and a "slow" state about 5 % apart were observed), which drowns small A/B effects
+        import json
+        import subprocess
+        for nm in names:
+            for o in opts:
+                subprocess.run([sys.executable, os.path.abspath(__file__), nm, "@one=" + json.dumps(o)])
+        sys.exit(0)
+    for a in sys.argv[1:]:
+        if a.startswith("@one="):
+            import json
+            opts = [json.loads(a[5:])]
     for nm in names:
         run(nm, opts)
