@@ -121,6 +121,9 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "spmv_deep")) c->deep_opt = value;
     else if (!strcmp(name, "tie_sort")) c->tie_sort_opt = value;
     else if (!strcmp(name, "pb_group")) c->pb_group_opt = value;
+    else if (!strcmp(name, "item_len")) c->item_opt = value;
+    else if (!strcmp(name, "stage_burst")) c->burst_opt = value;
+    else if (!strcmp(name, "narrow_slices")) c->narrow_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;

@@ -53,6 +53,9 @@ int lzx_graph_release(lzx_ctx *c)
     c->sx_send_off.clear();
     dev_free(c->d_slice_off);
     dev_free(c->d_slice_w);
+    dev_free(c->d_slice_perm);
+    c->ns_wide = c->ns_w8 = c->ns_w4 = 0;
+    c->h_slice_w0.clear();
     dev_free(c->d_sell_cols);
     dev_free(c->d_long_cols);
     dev_free(c->d_item_beg);
@@ -607,9 +610,10 @@ int lzx_graph_prepare(lzx_ctx *c)
         const u32 dp = round_up(degl[r], 4);
         h_long_ptr[r + 1] = h_long_ptr[r] + dp;
         h_item_first[r] = (u32)h_item_beg.size();
-        for (u32 b = 0; b < dp; b += LZX_ITEM) {
+        const u32 item_cap = c->item_opt > 0 ? (u32)c->item_opt : LZX_ITEM;
+        for (u32 b = 0; b < dp; b += item_cap) {
             h_item_beg.push_back(h_long_ptr[r] + b);
-            h_item_len.push_back(std::min(LZX_ITEM, dp - b));
+            h_item_len.push_back(std::min(item_cap, dp - b));
         }
     }
     h_item_first[c->n_long64] = (u32)h_item_beg.size();
@@ -640,6 +644,27 @@ int lzx_graph_prepare(lzx_ctx *c)
     PREP(dev_alloc(&c->d_item_first, (u64)c->n_long64 + 1));
     PREP(dev_alloc(&c->d_long_partial, c->n_items));
     PREP(dev_alloc(&d_long_ptr, (u64)c->n_long64 + 1));
+    {   // processing order of the slices: by class in blocked mode (k_spmv), as they lie otherwise
+        std::vector<u32> perm;
+        perm.reserve(c->n_slices);
+        c->h_slice_w0.clear();
+        const bool classes = pb && c->narrow_opt != 0;
+        for (u32 s2 = 0; s2 < c->n_slices; ++s2)
+            if (!classes || h_slice_w[s2] > 8) perm.push_back(s2);
+        c->ns_wide = (u32)perm.size();
+        for (u32 s2 = 0; classes && s2 < c->n_slices; ++s2)
+            if (h_slice_w[s2] == 8) perm.push_back(s2);
+        c->ns_w8 = (u32)perm.size() - c->ns_wide;
+        for (u32 s2 = 0; classes && s2 < c->n_slices; ++s2)
+            if (h_slice_w[s2] == 4) perm.push_back(s2);
+        c->ns_w4 = (u32)perm.size() - c->ns_wide - c->ns_w8;
+        for (u32 s2 = 0; classes && s2 < c->n_slices; ++s2)
+            if (h_slice_w[s2] == 0) { perm.push_back(s2); c->h_slice_w0.push_back(s2); }
+        PREP(dev_alloc(&c->d_slice_perm, c->n_slices));
+        if (c->n_slices)
+            PREP_HIP(hipMemcpyAsync(c->d_slice_perm, perm.data(), sizeof(u32) * c->n_slices, hipMemcpyHostToDevice, st));
+        PREP_HIP(hipStreamSynchronize(st));   // perm is a local
+    }
     if (c->n_slices) {
         PREP_HIP(hipMemcpyAsync(c->d_slice_off, h_slice_off.data(), sizeof(u64) * c->n_slices, hipMemcpyHostToDevice, st));
         PREP_HIP(hipMemcpyAsync(c->d_slice_w, h_slice_w.data(), sizeof(u32) * c->n_slices, hipMemcpyHostToDevice, st));

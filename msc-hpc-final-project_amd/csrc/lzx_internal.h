@@ -154,6 +154,11 @@ struct lzx_ctx {
     u64 sell_elems = 0;
     u64 *d_slice_off = nullptr;        // [n_slices] element offset of slice s in d_sell_cols
     u32 *d_slice_w = nullptr;          // [n_slices] width (multiple of 4)
+    // blocked mode: the staged-only slices are mostly 0 or 4 codes wide; they are processed class by class
+    u32 *d_slice_perm = nullptr;       // [n_slices] slice ids: wide ones (> 8 codes) in order, then width 8, width 4, width 0
+    u32 ns_wide = 0, ns_w8 = 0, ns_w4 = 0;
+    std::vector<u32> h_slice_w0;       // ids of the width-0 slices, ascending (their live prefix is counted per launch)
+    int64_t narrow_opt = -1;           // debug knob narrow_slices: 0 = every slice through the general loop
     bool codes16 = false;              // staged-only tables (propagation-blocking mode): 16-bit codes
     u32 *d_sell_cols = nullptr;
 
@@ -196,6 +201,8 @@ struct lzx_ctx {
     unsigned long long *d_pb_stamps = nullptr;   // [3][4096] debug library, option pb_stamps: per-workgroup start / end ticks
     int64_t pb_stamps_opt = -1;
     int64_t tie_sort_opt = -1;         // blocked mode: ties of the degree ranking broken by staged-column count (debug knob; 0 = by id)
+    int64_t item_opt = -1;             // entries per split-row item (debug knob; default LZX_ITEM)
+    int64_t burst_opt = -1;            // staged-columns kernel: staging loads all in flight (debug knob; 0 = one per iteration)
     int64_t deep_opt = -1;             // staged-columns kernel: 1 = four slices in flight instead of two (debug knob; no gain)
     int64_t pb_order_opt = -1;         // kernel order of the blocked SpMV (debug knob): -1/1 scatter, staged columns, gather; 0 staged columns first
     int64_t pb_group_opt = -1;         // values up to which a row band is gathered by ONE wavefront, eight such bands per workgroup item (debug knob; 0 = off)

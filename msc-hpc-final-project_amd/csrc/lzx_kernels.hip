@@ -13,6 +13,8 @@
 // reductions are closed in the PROLOGUE of the next kernel: every workgroup sums the same partials in the
 // same fixed order, so all of them hold bit-identical alpha / beta without global atomics, a separate
 // reduce launch or a grid barrier, and results are reproducible run to run.
+#include <type_traits>
+#include <algorithm>
 #include "lzx_internal.h"
 
 // --------------------------------------------------------------------------------------------------
@@ -43,7 +45,9 @@ struct SpmvArgs {
     const u32 *sell_cols;
     const u64 *slice_off;
     const u32 *slice_w;
-    u32 n_slices;
+    u32 n_slices;  // slices the general loop takes: entries [0, n_slices) of slice_perm
+    const u32 *slice_perm;   // processing order (blocked mode: wide slices, then the 8-, 4- and 0-code ones; identity otherwise)
+    u32 ns_w8, ns_w4, ns_w0; // blocked mode: how many of each narrow class follow in slice_perm
     u32 row0;  // first local row of the body (= rows handled as split rows)
     const u32 *long_cols;
     const u64 *item_beg;
@@ -60,6 +64,7 @@ struct SpmvArgs {
     u32 xs0;       // slice stride of chunk 0 of the exchange layout (the staged hub entries all live there)
     u32 n_zero;    // blocked mode: v[0 .. n_zero) (the split rows) starts at 0; the blocked passes and k_pb_finish add to it
     u32 deep;      // blocked mode: slices pipelined four deep instead of two
+    u32 burst;     // staging: eight loads per thread in flight (1) or one per loop iteration (0)
 };
 
 // Column code c: c < hub -> value staged in LDS slot c; otherwise x[c - hub].
@@ -68,6 +73,9 @@ struct SpmvArgs {
 template <int HUB>
 __device__ __forceinline__ double gather(u32 c, const double *__restrict__ x, const double *hubv, u32 hub)
 {
+#ifdef LZX_ABL_NOLDS   // ablation build (tools/): the staged value is not looked up
+    if (HUB == 2) return (double)c;
+#endif
     if (HUB == 2) return hubv[c];
     if (HUB) {
         if (c < hub) return hubv[c];
@@ -110,6 +118,27 @@ __device__ __forceinline__ uint4 load_idx4(const uint2 *p)
     }
     return make_uint4(r.x & 0xffffu, r.x >> 16, r.y & 0xffffu, r.y >> 16);
 }
+// the packet as it travels (blocked mode: 8 bytes = two registers) and its four codes, unpacked at the point of use:
+// twice as many packets fit the registers of a software pipeline
+template <bool NT>
+__device__ __forceinline__ uint4 load_raw(const uint4 *p) { return load_idx4<NT>(p); }
+template <bool NT>
+__device__ __forceinline__ uint2 load_raw(const uint2 *p)
+{
+#ifdef LZX_ABL_NOLOAD   // ablation build (tools/): the packet is not loaded
+    return make_uint2((u32)(size_t)p & 0x3fff3fffu, ((u32)(size_t)p >> 3) & 0x3fff3fffu);
+#endif
+    uint2 r;
+    if (NT) {
+        r.x = __builtin_nontemporal_load(&p->x);
+        r.y = __builtin_nontemporal_load(&p->y);
+    } else {
+        r = *p;
+    }
+    return r;
+}
+__device__ __forceinline__ uint4 codes_of(const uint4 &r) { return r; }
+__device__ __forceinline__ uint4 codes_of(const uint2 &r) { return make_uint4(r.x & 0xffffu, r.x >> 16, r.y & 0xffffu, r.y >> 16); }
 template <int HUB> struct CodeTable { using packet = uint4; using code = u32; };
 template <> struct CodeTable<2> { using packet = uint2; using code = uint16_t; };
 
@@ -130,10 +159,49 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
     if (HUB) {
         // Stage x of the `hub` highest-degree vertices once per workgroup (coalesced at world == 1;
         // `world` strided segments otherwise: degree rank r lives at (r % world) * xs0 + r / world, in chunk 0).
-        for (u32 i = tid; i < a.hub; i += LZX_SPMV_BLOCK) {
-            const u32 g = (a.world == 1) ? i : (i % a.world) * a.xs0 + i / a.world;
-            hubv[i] = i < a.hub_real ? a.x[g] : 0.0;
+        // Staging is dead time for the CU (one workgroup fits beside the tile): every thread issues eight loads before
+        // its first LDS write, so 16 Ki values cost one or two memory round trips instead of sixteen (a load per loop
+        // iteration, each waited for, was 20 us of the 110 us this kernel took on the 10 M-vertex graph).
+        if (!a.burst) {
+            for (u32 i = tid; i < a.hub_real; i += LZX_SPMV_BLOCK) {
+                const u32 g = (a.world == 1) ? i : (i % a.world) * a.xs0 + i / a.world;
+                hubv[i] = a.x[g];
+            }
+        } else if (a.world == 1) {
+            const u32 pairs = a.hub_real >> 1;               // hub_real is even; x is 16-byte aligned
+            const double2 *src = reinterpret_cast<const double2 *>(a.x);
+            for (u32 i0 = 0; i0 < pairs; i0 += 8 * LZX_SPMV_BLOCK) {
+                // clamped index, unconditional load AND store (a store under `if` pulls its load into the branch, and the
+                // eight round trips are serial again); threads past the end rewrite the last pair with its own value
+                double2 t[8];
+#pragma unroll
+                for (u32 u = 0; u < 8; ++u) {
+                    const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
+                    t[u] = src[i < pairs ? i : pairs - 1];
+                }
+#pragma unroll
+                for (u32 u = 0; u < 8; ++u) {
+                    const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
+                    reinterpret_cast<double2 *>(hubv)[i < pairs ? i : pairs - 1] = t[u];
+                }
+            }
+        } else {
+            for (u32 i0 = 0; i0 < a.hub_real; i0 += 8 * LZX_SPMV_BLOCK) {
+                double t[8];
+#pragma unroll
+                for (u32 u = 0; u < 8; ++u) {
+                    const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
+                    const u32 j = i < a.hub_real ? i : a.hub_real - 1;
+                    t[u] = a.x[(j % a.world) * a.xs0 + j / a.world];
+                }
+#pragma unroll
+                for (u32 u = 0; u < 8; ++u) {
+                    const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
+                    hubv[i < a.hub_real ? i : a.hub_real - 1] = t[u];
+                }
+            }
         }
+        for (u32 i = a.hub_real + tid; i < a.hub; i += LZX_SPMV_BLOCK) hubv[i] = 0.0;
         __syncthreads();
     }
 
@@ -164,63 +232,53 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
             const u32 di = w0 + (base + (lane < cnt ? lane : 0)) * waves;
             const u64 d_beg = a.item_beg[di];
             const u32 d_pk = a.item_len[di] >> 2;
-            auto issue = [&](u32 j, uint4 &k0, uint4 &k1) {
+            // IPF packets of an item (per lane) are in flight ahead of its summation, in two register sets (2 -> 4 -> 8:
+            // the split-row part of the 10 M-vertex graph 33 -> 28 -> .. us: it is bound by bytes in flight per wavefront)
+            constexpr int IPF = HUB == 2 ? 8 : 4;
+            auto issue = [&](u32 j, PK (&kk)[IPF]) {
                 const PK *p = reinterpret_cast<const PK *>(long_cols + lane_u64(d_beg, j));
                 const u32 packets = lane_u32(d_pk, j);
-                k0 = load_idx4<NT>(p + (lane < packets ? lane : 0));
-                k1 = load_idx4<NT>(p + (lane + 64 < packets ? lane + 64 : 0));
+#pragma unroll
+                for (int u = 0; u < IPF; ++u) kk[u] = load_raw<NT>(p + (lane + 64u * u < packets ? lane + 64u * u : 0));
             };
-            auto consume = [&](u32 j, const uint4 &k0, const uint4 &k1) {
+            auto add4 = [&](const PK &raw, double &acc) {
+                const uint4 k = codes_of(raw);
+                const double x0 = gather<HUB>(k.x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(k.y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(k.z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(k.w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            };
+            auto consume = [&](u32 j, const PK (&kk)[IPF]) {
                 const PK *p = reinterpret_cast<const PK *>(long_cols + lane_u64(d_beg, j));
                 const u32 packets = lane_u32(d_pk, j);
                 double acc = 0.0;
-                if (lane < packets) {
-                    const double x0 = gather<HUB>(k0.x, a.x, hubv, a.hub);
-                    const double x1 = gather<HUB>(k0.y, a.x, hubv, a.hub);
-                    const double x2 = gather<HUB>(k0.z, a.x, hubv, a.hub);
-                    const double x3 = gather<HUB>(k0.w, a.x, hubv, a.hub);
-                    acc += x0; acc += x1; acc += x2; acc += x3;
-                }
-                if (lane + 64 < packets) {
-                    const double x0 = gather<HUB>(k1.x, a.x, hubv, a.hub);
-                    const double x1 = gather<HUB>(k1.y, a.x, hubv, a.hub);
-                    const double x2 = gather<HUB>(k1.z, a.x, hubv, a.hub);
-                    const double x3 = gather<HUB>(k1.w, a.x, hubv, a.hub);
-                    acc += x0; acc += x1; acc += x2; acc += x3;
-                }
-                u32 q = lane + 128;
-                for (; q + 64 < packets; q += 128) {
-                    const uint4 c = load_idx4<NT>(p + q), e = load_idx4<NT>(p + q + 64);
-                    const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
-                    const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
-                    const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
-                    const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
-                    const double x4 = gather<HUB>(e.x, a.x, hubv, a.hub);
-                    const double x5 = gather<HUB>(e.y, a.x, hubv, a.hub);
-                    const double x6 = gather<HUB>(e.z, a.x, hubv, a.hub);
-                    const double x7 = gather<HUB>(e.w, a.x, hubv, a.hub);
-                    acc += x0; acc += x1; acc += x2; acc += x3;
-                    acc += x4; acc += x5; acc += x6; acc += x7;
+#pragma unroll
+                for (int u = 0; u < IPF; ++u)
+                    if (lane + 64u * u < packets) add4(kk[u], acc);
+                u32 q = lane + 64u * IPF;
+                for (; q + 64u * 3 < packets; q += 64u * 4) {
+                    PK c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c[u] = load_raw<NT>(p + q + 64u * u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) add4(c[u], acc);
                 }
                 for (; q < packets; q += 64) {
-                    const uint4 c = load_idx4<NT>(p + q);
-                    const double x0 = gather<HUB>(c.x, a.x, hubv, a.hub);
-                    const double x1 = gather<HUB>(c.y, a.x, hubv, a.hub);
-                    const double x2 = gather<HUB>(c.z, a.x, hubv, a.hub);
-                    const double x3 = gather<HUB>(c.w, a.x, hubv, a.hub);
-                    acc += x0; acc += x1; acc += x2; acc += x3;
+                    const PK c = load_raw<NT>(p + q);
+                    add4(c, acc);
                 }
                 acc = wave_sum(acc);
                 if (lane == 0) a.long_partial[w0 + (base + j) * waves] = acc;
             };
-            uint4 a0, a1, b0, b1;
-            issue(0, a0, a1);
+            PK ka[IPF], kb[IPF];
+            issue(0, ka);
             for (u32 j = 0; j < cnt; j += 2) {
-                issue(j + 1 < cnt ? j + 1 : j, b0, b1);
-                consume(j, a0, a1);
+                issue(j + 1 < cnt ? j + 1 : j, kb);
+                consume(j, ka);
                 if (j + 1 >= cnt) break;
-                issue(j + 2 < cnt ? j + 2 : j + 1, a0, a1);
-                consume(j + 1, b0, b1);
+                issue(j + 2 < cnt ? j + 2 : j + 1, ka);
+                consume(j + 1, kb);
             }
         }
     }
@@ -234,63 +292,57 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
         for (u32 base = 0; base < mine; base += 64) {
             const u32 cnt = mine - base < 64 ? mine - base : 64;
             const u32 di = w0 + (base + (lane < cnt ? lane : 0)) * waves;
-            const u64 d_off = a.slice_off[di];
-            const u32 d_st = a.slice_w[di] >> 2;   // packets per lane
-            // PF packets of a slice are fetched ahead of its summation (8 instead of 4 changed nothing in blocked mode)
+            const u32 d_sid = a.slice_perm[di];    // which 64 rows
+            const u64 d_off = a.slice_off[d_sid];
+            const u32 d_st = a.slice_w[d_sid] >> 2;   // packets per lane
+            // PF packets of a slice are fetched ahead of its summation; beyond them a wide slice streams GP packets at a time
             constexpr int PF = 4;
-            auto issue = [&](u32 j, uint4 (&f)[PF], double &qrow) {
+            constexpr int GP = HUB == 2 ? 8 : 4;
+            auto issue = [&](u32 j, PK (&f)[PF], double &qrow) {
                 const PK *p = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, j)) + lane;
                 const u32 st = lane_u32(d_st, j);
 #pragma unroll
-                for (int u = 0; u < PF; ++u) f[u] = load_idx4<NT>(p + (size_t)((u32)u < st ? u : 0) * 64);
-                qrow = a.q_loc[a.row0 + (w0 + (base + j) * waves) * 64 + lane];
+                for (int u = 0; u < PF; ++u) f[u] = load_raw<NT>(p + (size_t)((u32)u < st ? u : 0) * 64);
+                qrow = a.q_loc[a.row0 + lane_u32(d_sid, j) * 64 + lane];
             };
-            auto consume = [&](u32 j, const uint4 (&f)[PF], double qrow) {
+            auto add4 = [&](const PK &raw, double &acc) {   // left to right: the reference's order
+                const uint4 k = codes_of(raw);
+                const double x0 = gather<HUB>(k.x, a.x, hubv, a.hub);
+                const double x1 = gather<HUB>(k.y, a.x, hubv, a.hub);
+                const double x2 = gather<HUB>(k.z, a.x, hubv, a.hub);
+                const double x3 = gather<HUB>(k.w, a.x, hubv, a.hub);
+                acc += x0; acc += x1; acc += x2; acc += x3;
+            };
+            auto consume = [&](u32 j, const PK (&f)[PF], double qrow) {
                 const PK *p = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, j)) + lane;
                 const u32 st = lane_u32(d_st, j);
                 double acc = 0.0;
 #pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    if ((u32)u < st) {
-                        const double x0 = gather<HUB>(f[u].x, a.x, hubv, a.hub);
-                        const double x1 = gather<HUB>(f[u].y, a.x, hubv, a.hub);
-                        const double x2 = gather<HUB>(f[u].z, a.x, hubv, a.hub);
-                        const double x3 = gather<HUB>(f[u].w, a.x, hubv, a.hub);
-                        acc += x0; acc += x1; acc += x2; acc += x3;   // left to right: the reference's order
-                    }
-                }
+                for (int u = 0; u < PF; ++u)
+                    if ((u32)u < st) add4(f[u], acc);
                 u32 i = PF;
-                for (; i + 4 <= st; i += 4) {
-                    uint4 c[4];
+                for (; i + GP <= st; i += GP) {
+                    PK c[GP];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) c[u] = load_idx4<NT>(p + (size_t)(i + u) * 64);
-                    double xv[16];
+                    for (int u = 0; u < GP; ++u) c[u] = load_raw<NT>(p + (size_t)(i + u) * 64);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        xv[4 * u + 0] = gather<HUB>(c[u].x, a.x, hubv, a.hub);
-                        xv[4 * u + 1] = gather<HUB>(c[u].y, a.x, hubv, a.hub);
-                        xv[4 * u + 2] = gather<HUB>(c[u].z, a.x, hubv, a.hub);
-                        xv[4 * u + 3] = gather<HUB>(c[u].w, a.x, hubv, a.hub);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += xv[u];
+                    for (int u = 0; u < GP; ++u) add4(c[u], acc);
                 }
-                for (; i < st; ++i) {
-                    const uint4 c0 = load_idx4<NT>(p + (size_t)i * 64);
-                    const double x0 = gather<HUB>(c0.x, a.x, hubv, a.hub);
-                    const double x1 = gather<HUB>(c0.y, a.x, hubv, a.hub);
-                    const double x2 = gather<HUB>(c0.z, a.x, hubv, a.hub);
-                    const double x3 = gather<HUB>(c0.w, a.x, hubv, a.hub);
-                    acc += x0; acc += x1; acc += x2; acc += x3;
+                if (i < st) {   // up to GP - 1 more packets: wave-uniform count, all in flight together
+                    PK c[GP - 1];
+#pragma unroll
+                    for (int u = 0; u < GP - 1; ++u) c[u] = load_raw<NT>(p + (size_t)(i + u < st ? i + u : i) * 64);
+#pragma unroll
+                    for (int u = 0; u < GP - 1; ++u)
+                        if (i + u < st) add4(c[u], acc);
                 }
-                a.v[a.row0 + (w0 + (base + j) * waves) * 64 + lane] = acc;
+                a.v[a.row0 + lane_u32(d_sid, j) * 64 + lane] = acc;
                 dot += acc * qrow;
             };
             if (HUB == 2 && a.deep) {
-                // blocked mode: the staged-only slices are short (a few hundred clocks of work each) and the kernel waits on
-                // memory round trips, not bandwidth (SQ_WAIT_ANY 70 %): the packets of the next THREE slices are in flight
-                // while one is summed -- four register sets used in rotation, every load from a clamped, valid address
-                uint4 f0[PF], f1[PF], f2[PF], f3[PF];
+                // experiment (debug knob spmv_deep): the packets of the next THREE slices in flight while one is summed --
+                // four register sets used in rotation, every load from a clamped, valid address
+                PK f0[PF], f1[PF], f2[PF], f3[PF];
                 double q0, q1, q2, q3;
                 const u32 lastj = cnt - 1;
                 auto at = [&](u32 j) { return j < cnt ? j : lastj; };
@@ -311,18 +363,68 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
                     consume(j + 3, f3, q3);
                 }
             } else {
-            uint4 fa[PF], fb[PF];
-            double qa, qb;
-            issue(0, fa, qa);
-            for (u32 j = 0; j < cnt; j += 2) {
-                issue(j + 1 < cnt ? j + 1 : j, fb, qb);
-                consume(j, fa, qa);
-                if (j + 1 >= cnt) break;
-                issue(j + 2 < cnt ? j + 2 : j + 1, fa, qa);
-                consume(j + 1, fb, qb);
-            }
+                PK fa[PF], fb[PF];
+                double qa, qb;
+                issue(0, fa, qa);
+                for (u32 j = 0; j < cnt; j += 2) {
+                    issue(j + 1 < cnt ? j + 1 : j, fb, qb);
+                    consume(j, fa, qa);
+                    if (j + 1 >= cnt) break;
+                    issue(j + 2 < cnt ? j + 2 : j + 1, fa, qa);
+                    consume(j + 1, fb, qb);
+                }
             }
         }
+    }
+
+    // ---- blocked mode: the narrow staged-only slices.  Two thirds of the slices of a large R-MAT graph hold 0 or 4 codes per
+    //      row (low-degree rows have one or two staged neighbours, a fifth of the rows none): through the general loop
+    //      each cost its ~150 instructions of descriptor, pipeline and tail handling plus four clamped loads -- three
+    //      quarters of that loop's instruction stream for a seventh of its entries.  Here: four slices per step, their
+    //      packets and q values all in flight together, no pipeline state across steps.
+    if (HUB == 2) {
+        auto narrow = [&](u32 first, u32 count, auto np_tag) {
+            constexpr int NP = decltype(np_tag)::value;
+            const u32 mine = count > w0 ? (count - w0 + waves - 1) / waves : 0;
+            for (u32 base = 0; base < mine; base += 64) {
+                const u32 cnt = mine - base < 64 ? mine - base : 64;
+                const u32 d_sid = a.slice_perm[first + w0 + (base + (lane < cnt ? lane : 0)) * waves];
+                const u64 d_off = NP ? a.slice_off[d_sid] : 0;
+                for (u32 j = 0; j < cnt; j += 4) {
+                    PK f[4][NP ? NP : 1];
+                    double qr[4];
+                    u32 row[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 jj = j + u < cnt ? j + u : cnt - 1;   // clamped: unconditional loads
+                        row[u] = a.row0 + lane_u32(d_sid, jj) * 64 + lane;
+                        if (NP) {
+                            const PK *pp = reinterpret_cast<const PK *>(sell_cols + lane_u64(d_off, jj)) + lane;
+#pragma unroll
+                            for (int e = 0; e < NP; ++e) f[u][e] = load_raw<NT>(pp + (size_t)e * 64);
+                            qr[u] = a.q_loc[row[u]];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u < cnt) {   // wave-uniform
+                            double acc = 0.0;
+#pragma unroll
+                            for (int e = 0; e < NP; ++e) {
+                                const uint4 k = codes_of(f[u][e]);
+                                const double x0 = hubv[k.x], x1 = hubv[k.y], x2 = hubv[k.z], x3 = hubv[k.w];
+                                acc += x0; acc += x1; acc += x2; acc += x3;
+                            }
+                            a.v[row[u]] = acc;
+                            if (NP) dot += acc * qr[u];
+                        }
+                    }
+                }
+            }
+        };
+        narrow(a.n_slices, a.ns_w8, std::integral_constant<int, 2>{});
+        narrow(a.n_slices + a.ns_w8, a.ns_w4, std::integral_constant<int, 1>{});
+        narrow(a.n_slices + a.ns_w8 + a.ns_w4, a.ns_w0, std::integral_constant<int, 0>{});
     }
 
     dot = wave_sum(dot);
@@ -586,9 +688,16 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.sell_cols = c->d_sell_cols;
     a.slice_off = c->d_slice_off;
     a.slice_w = c->d_slice_w;
-    a.n_slices = (c->phase_mask_opt & 2) ? c->n_slices : 0;
-    if (l.live_rows_only)   // slices of rows without an edge: nothing to sum, and the caller does not read their v
-        a.n_slices = std::min<u32>(a.n_slices, c->rows_live > c->n_long64 ? (c->rows_live - c->n_long64) / LZX_SLICE : 0u);
+    // slices of rows without an edge (live_rows_only): nothing to sum, and the caller does not read their v
+    const u32 live_slices = l.live_rows_only ? (c->rows_live > c->n_long64 ? (c->rows_live - c->n_long64) / LZX_SLICE : 0u) : c->n_slices;
+    a.slice_perm = c->d_slice_perm;
+    a.ns_w8 = c->ns_w8;
+    a.ns_w4 = c->ns_w4;
+    // the width-0 slices with rows that are read later: a prefix of their ascending id list
+    a.ns_w0 = (u32)(std::lower_bound(c->h_slice_w0.begin(), c->h_slice_w0.end(), live_slices) - c->h_slice_w0.begin());
+    a.n_slices = c->ns_wide;
+    if (c->ns_wide == c->n_slices) a.n_slices = std::min<u32>(c->n_slices, live_slices);   // no classes: slices as they lie
+    if (!(c->phase_mask_opt & 2)) a.n_slices = a.ns_w8 = a.ns_w4 = a.ns_w0 = 0;
     a.row0 = c->n_long64;
     a.long_cols = c->d_long_cols;
     a.item_beg = c->d_item_beg;
@@ -604,6 +713,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.world = (u32)c->world;
     a.xs0 = c->xs0;
     a.n_zero = c->pb ? c->n_long64 : 0;
+    a.burst = c->burst_opt > 0 ? 1u : 0u;   // debug knob stage_burst: all loads in flight was 8 us SLOWER (256 CUs hit the same 128 KiB at once), off
     a.deep = c->deep_opt > 0 ? 1u : 0u;   // debug knob spmv_deep: no gain measured (DESIGN.md 3.1 g), off
     const bool nt = c->nt_opt > 0;
     // Blocked mode, option "side_stream": the staged-columns kernel and the scatter passes are independent (both only

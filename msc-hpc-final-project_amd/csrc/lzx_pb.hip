@@ -365,6 +365,24 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
     // staging is dead time for this CU (the tile leaves room for one workgroup): all eight 16-byte loads of a
     // thread are issued before the first LDS write, so it costs one memory round trip
     if (ablate == 10) {
+    } else if (ablate == 11 && base + CB <= xlen) {   // one 16-byte load per round trip (staging experiment)
+        const double2 *src = reinterpret_cast<const double2 *>(x + base);
+        for (u32 u = 0; u < CB / 2048; ++u) {
+            const double2 t = src[threadIdx.x + u * 1024];
+            reinterpret_cast<double2 *>(tile)[threadIdx.x + u * 1024] = t;
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+    } else if (ablate == 12 && base + CB <= xlen) {   // two round trips of four loads
+        const double2 *src = reinterpret_cast<const double2 *>(x + base);
+#pragma unroll
+        for (u32 h = 0; h < 2; ++h) {
+            double2 t[CB / 4096];
+#pragma unroll
+            for (u32 u = 0; u < CB / 4096; ++u) t[u] = src[threadIdx.x + (h * (CB / 4096) + u) * 1024];
+#pragma unroll
+            for (u32 u = 0; u < CB / 4096; ++u) reinterpret_cast<double2 *>(tile)[threadIdx.x + (h * (CB / 4096) + u) * 1024] = t[u];
+            __builtin_amdgcn_s_waitcnt(0);
+        }
     } else if (base + CB <= xlen) {
         const double2 *src = reinterpret_cast<const double2 *>(x + base);   // band starts are 128 KiB aligned
         double2 t[CB / 2048];

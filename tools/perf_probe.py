@@ -9,6 +9,8 @@ import numpy as np
 import __graft_entry__ as ge
 
 pkg = ge.load_pkg()
+if os.environ.get("LZX_PROBE_DBG_LIB"):   # A/B against another build of the debug library (same box, same job)
+    pkg.DBG_LIB_PATH = os.environ["LZX_PROBE_DBG_LIB"]
 WORK = {"c2": (20, 1 << 20, 20_000_000), "c3": (24, 10_000_000, 200_000_000), "c2b": (20, 1_000_000, 20_000_000),
         "big": (25, 30_000_000, 600_000_000), "c5": (27, 100_000_000, 2_000_000_000)}
 
@@ -47,6 +49,17 @@ if __name__ == "__main__":
         opts = [dict(tie_sort=1), dict(tie_sort=2), dict(tie_sort=0), dict(tie_sort=1), dict(tie_sort=2), dict(tie_sort=0)]
     if "grp" in sets:
         opts = [dict(pb_group=16384), dict(pb_group=0), dict(pb_group=8192), dict(pb_group=12288), dict(pb_group=20480), dict(pb_group=24576), dict(pb_group=16384), dict(pb_group=0)]
+    if "stg" in sets:
+        opts = [dict(pb_order=0), dict(pb_order=0, phase_mask=1), dict(pb_order=0, phase_mask=2), dict(pb_order=0, phase_mask=2, long_row=100000), dict(pb_order=1)]
+    if "itm" in sets:
+        opts = [dict(pb_order=0, phase_mask=1), dict(pb_order=0, phase_mask=2), dict(pb_order=0), dict(pb_order=0, spmv_deep=1), dict(pb_order=1)]
+    if "base" in sets:
+        opts = [dict(pb_order=1), dict(pb_order=0), dict(pb_order=1), dict(pb_order=0)]
+    if "burst" in sets:
+        opts = [dict(pb_order=0, stage_burst=1, phase_mask=0), dict(pb_order=0, stage_burst=0, phase_mask=0)] * 2
+    if "nar" in sets:
+        opts = [dict(pb_order=0, narrow_slices=1), dict(pb_order=0, narrow_slices=0), dict(pb_order=0, narrow_slices=1, phase_mask=2), dict(pb_order=0, narrow_slices=0, phase_mask=2),
+                dict(narrow_slices=1), dict(narrow_slices=0)]
     if "grp2" in sets:
         opts = [dict(pb_group=16384), dict(pb_group=0)] * 4
     if "deep" in sets:
