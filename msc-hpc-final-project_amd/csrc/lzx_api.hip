@@ -75,6 +75,7 @@ extern "C" void lzx_destroy(lzx_handle c)
     if (c->d_alpha) (void)hipFree(c->d_alpha);
     if (c->d_beta) (void)hipFree(c->d_beta);
     if (c->d_scal) (void)hipFree(c->d_scal);
+    if (c->d_iso) (void)hipFree(c->d_iso);
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -124,6 +125,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "item_len")) c->item_opt = value;
     else if (!strcmp(name, "stage_burst")) c->burst_opt = value;
     else if (!strcmp(name, "narrow_slices")) c->narrow_opt = value;
+    else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
@@ -266,6 +268,16 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
             LZX_HIP(hipMemcpyAsync(c->d_Q, c->d_ybuf + (size_t)c->rank * c->n_loc_pad,
                                    sizeof(double) * c->n_loc_pad, hipMemcpyDeviceToDevice, c->stream));
             LZX_TRY(lzx_launch_relayout(c, c->d_ybuf, c->d_xbuf));
+        }
+    }
+    // the lazy loop (lanczos_loop) carries the rows without an edge as one scalar recurrence
+    {
+        const bool lazy = c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (multi || c0->codes16));
+        for (lzx_ctx *c : cs) {
+            LZX_HIP(hipSetDevice(c->device));
+            c->iso_on = lazy && c->iso_opt != 0;
+            c->iso_filled = false;
+            if (c->iso_on) LZX_TRY(lzx_launch_iso_prepare(c, k));
         }
     }
     LZX_TRY(sync_all(cs));
@@ -548,6 +560,13 @@ static int lanczos_fetch(std::vector<lzx_ctx *> &cs, u32 k, double *alpha, doubl
     if (k > 1) LZX_HIP(hipMemcpy(beta, c0->d_beta, sizeof(double) * (k - 1), hipMemcpyDeviceToHost));
 
     if (Q) {
+        // rows without an edge are kept as scalars times q_0 by the lazy loop: written out once somebody wants the basis
+        for (lzx_ctx *c : cs) {
+            if (!c->iso_on || c->iso_filled) continue;
+            LZX_HIP(hipSetDevice(c->device));
+            LZX_TRY(lzx_launch_iso_fill(c, c->k_last));
+            c->iso_filled = true;
+        }
         // k contiguous vectors in the caller's vertex order (cu_lanczos.cu:126 layout)
         for (u32 j = 0; j < k; ++j) {
             if (multi) {

@@ -220,6 +220,14 @@ struct lzx_ctx {
     // vectors and scalars
     double *d_v = nullptr;             // [ldq]
     u32 np2_last = 0;                  // partials the last k_lazy_update left in d_partials2
+    // Rows without an edge (the tail of every slice, [rows_live, n_loc_pad)) in the lazy loop: (A u)_i = 0 there, so
+    // q_j[i] = c_j q_0[i] with ONE scalar recurrence for all of them (k_lazy_update, block 0); the loop neither reads nor
+    // writes them, lzx_multout uses the scalars, a host fetch of the basis materialises them first.
+    bool iso_on = false;               // the last prepared decomposition runs in that form
+    bool iso_filled = false;           // ... and its basis columns 1.. have been materialised for those rows
+    double *d_iso = nullptr;           // [2 k_cap + 4]: c_j at [j], d_j (the same for the unnormalised u_j) at [k_cap + 1 + j]; last: sum of q_0[i]^2 over those rows
+    u32 iso_cap = 0;
+    int64_t iso_opt = -1;              // debug knob isolated_rows: 0 = elementwise like every other row
     double *d_u[2] = {nullptr, nullptr};   // [ldq] each, several ranks: the unnormalised Lanczos vector, alternating (lzx_api.hip)
     double *d_Q = nullptr;             // [q_cols][ldq]
     u32 q_cols = 0;
@@ -271,6 +279,8 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &a);
 u32 lzx_spmv_partials(const lzx_ctx *c);
 int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, int do_sqrt);
 int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, double *out2);
+int lzx_launch_iso_prepare(lzx_ctx *c, u32 k);                       // sum of squares of q_0 over the rows without an edge, c_0 = d_0 = 1
+int lzx_launch_iso_fill(lzx_ctx *c, u32 k);                          // q_j[i] = c_j q_0[i] for those rows, j = 1 .. k - 1
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out);
 int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,

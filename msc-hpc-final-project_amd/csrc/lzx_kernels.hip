@@ -509,7 +509,7 @@ k_axpy_norm(double *v, const double *__restrict__ qj, const double *__restrict__
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict__ u, const double *__restrict__ q_prev,
               const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
-              double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n)
+              double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n, double *iso, u32 iso_k, u32 iso_j)
 {
     __shared__ double sh[4];
     double D, B;
@@ -526,6 +526,20 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *alpha_out = alpha;
         if (beta_out) *beta_out = beta;
+        if (iso) {
+            // the rows without an edge (this launch covers [0, n) only): q_j = c_j q_0, u_j = d_j q_0 there, and the update
+            // below with w = 0 is one scalar recurrence, rounded where the elementwise form rounds; their share of
+            // ||u_{j+1}||^2 goes into one more partial
+            const double cj = first ? 1.0 : iso[iso_k + 1 + iso_j] / beta;
+            iso[iso_j] = cj;
+            if (u_next) {
+                double t = 0.0;
+                t -= alpha * cj;
+                if (q_prev) t -= beta * iso[iso_j - 1];
+                iso[iso_k + 1 + iso_j + 1] = t;
+                partials_out[gridDim.x] = (t * t) * iso[2 * iso_k + 3];
+            }
+        }
     }
     double nrm = 0.0;
     const u32 stride = gridDim.x * LZX_VEC_BLOCK * 2;
@@ -651,14 +665,54 @@ __global__ void k_permute_out(const double *full, const u32 *gidx, double *io, u
 
 // ans_loc = Q_loc t: the second dgemv of multOut (parallel-final/lib/multiplyOut.cu:42-44), on the
 // device-resident basis; one thread per row, basis vectors streamed with unit stride.
+// iso != nullptr: rows [rows_act, n) are kept as q_j[i] = iso[j] q_0[i] (lzx_internal.h: iso_on).
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
-k_multout(const double *Q, u32 ldq, const double *t, u32 k, double *out, u32 n)
+k_multout(const double *Q, u32 ldq, const double *t, u32 k, double *out, u32 n, u32 rows_act, const double *iso)
 {
     const u32 i = blockIdx.x * LZX_VEC_BLOCK + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
-    for (u32 j = 0; j < k; ++j) s += Q[(size_t)j * ldq + i] * t[j];
+    if (iso && i >= rows_act) {
+        const double z = Q[i];
+        for (u32 j = 0; j < k; ++j) s += (j ? iso[j] * z : z) * t[j];
+    } else {
+        for (u32 j = 0; j < k; ++j) s += Q[(size_t)j * ldq + i] * t[j];
+    }
     out[i] = s;
+}
+
+// sum of q_0[i]^2 over rows [r0, r1) in two fixed-shape steps (per-block partials, then one block); also c_0 = d_0 = 1
+__global__ void __launch_bounds__(LZX_VEC_BLOCK)
+k_iso_sumsq(const double *q0, u32 r0, u32 r1, double *partials)
+{
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (u32 i = r0 + blockIdx.x * LZX_VEC_BLOCK + threadIdx.x; i < r1; i += gridDim.x * LZX_VEC_BLOCK) s += q0[i] * q0[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+__global__ void __launch_bounds__(LZX_VEC_BLOCK)
+k_iso_prepare(const double *partials, u32 np, double *iso, u32 iso_k)
+{
+    __shared__ double sh[4];
+    const double t = block_sum_fixed_256(partials, np, sh);
+    if (threadIdx.x == 0) {
+        iso[2 * iso_k + 3] = t;
+        iso[0] = 1.0;
+        iso[iso_k + 1] = 1.0;
+    }
+}
+
+// basis columns 1 .. k-1 of the rows without an edge, materialised: q_j[i] = c_j q_0[i]
+__global__ void k_iso_fill(double *Q, u32 ldq, u32 k, u32 r0, u32 r1, const double *iso)
+{
+    const u32 i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r1) return;
+    const double z = Q[i];
+    for (u32 j = 1; j < k; ++j) Q[(size_t)j * ldq + i] = iso[j] * z;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -789,9 +843,10 @@ int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double
 {
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
-                       first, alpha_out, beta_out, q_out, u_next, partials_out, c->n_loc_pad);
+                       first, alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha));
     LZX_HIP(hipGetLastError());
-    *np_out = g;
+    *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
 }
 
@@ -801,9 +856,10 @@ int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const 
 {
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, nullptr, pa, na, pb, nb, first,
-                       alpha_out, beta_out, q_out, u_next, partials_out, c->n_loc_pad);
+                       alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha));
     LZX_HIP(hipGetLastError());
-    *np_out = g;
+    *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
 }
 
@@ -887,8 +943,36 @@ int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_la
 int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc)
 {
     const u32 g = (c->n_loc_pad + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
+    const bool factored = c->iso_on && !c->iso_filled;
     hipLaunchKernelGGL(k_multout, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Q, c->ldq, t_dev, k,
-                       out_loc, c->n_loc_pad);
+                       out_loc, c->n_loc_pad, c->rows_live, factored ? c->d_iso : nullptr);
     LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_iso_prepare(lzx_ctx *c, u32 k)
+{
+    if (c->iso_cap < k || !c->d_iso) {
+        if (c->d_iso) (void)hipFree(c->d_iso);
+        c->d_iso = nullptr;
+        c->iso_cap = 0;
+        LZX_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_iso), sizeof(double) * (2 * (size_t)k + 4)));
+        c->iso_cap = k;
+    }
+    LZX_HIP(hipMemsetAsync(c->d_iso, 0, sizeof(double) * (2 * (size_t)c->iso_cap + 4), c->stream));
+    const u32 g = std::min<u32>(256u, c->np_cap);
+    hipLaunchKernelGGL(k_iso_sumsq, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Q, c->rows_live, c->n_loc_pad, c->d_partials3);
+    hipLaunchKernelGGL(k_iso_prepare, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_partials3, g, c->d_iso, c->iso_cap);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_iso_fill(lzx_ctx *c, u32 k)
+{
+    if (k > 1 && c->n_loc_pad > c->rows_live) {
+        const u32 rows = c->n_loc_pad - c->rows_live;
+        hipLaunchKernelGGL(k_iso_fill, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Q, c->ldq, k, c->rows_live, c->n_loc_pad, c->d_iso);
+        LZX_HIP(hipGetLastError());
+    }
     return LZX_OK;
 }

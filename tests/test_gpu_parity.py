@@ -195,6 +195,57 @@ def test_edge_ingest_matches_loader(oracle, engine_factory, tmp_path):
     eng.close()
 
 
+def test_rows_without_an_edge_as_one_scalar_recurrence(oracle, pkg):
+    """The lazy loop (blocked mode on one GPU, every mode on several) neither reads nor writes the rows of vertices
+    without an edge: (A u)_i = 0 there, so q_j[i] = c_j q_0[i] with one scalar recurrence for all of them
+    (k_lazy_update).  With a NON-constant start vector: the basis rows of those vertices against the oracle's
+    elementwise ones (serial/lib/lanczos.cc:26-44), their share of the norms through alpha / beta, the device multOut in
+    its factored form (before anybody fetched the basis) and after the basis has been materialised."""
+    O = oracle
+    rp, ci = O.gen_rmat(15, 30000, 120000, 11)       # about half of the vertices have no edge
+    n, k = len(rp) - 1, 14
+    deg = np.diff(rp.astype(np.int64))
+    iso = deg == 0
+    assert 0.3 * n < iso.sum() < 0.8 * n
+    x0 = 0.5 + np.random.default_rng(17).random(n)
+    a_ref, b_ref, Q_ref, xn_ref, ans_ref = pipeline_ref(O, rp, ci, k, x0)
+    lam_ref, V_ref = O.eigen(a_ref, b_ref)
+    t = V_ref @ (np.exp(lam_ref) * (xn_ref * V_ref[0, :]))
+    assert np.isfinite(ans_ref).all()
+
+    def check(eng, name):
+        eng.set_graph_csr(rp, ci)
+        xn = eng.lanczos_prepare(x0, k)
+        eng.lanczos_run()
+        assert xn == xn_ref
+        ans_factored = eng.multout(t)                  # nobody has asked for the basis yet
+        a, b, Q = eng.lanczos_fetch(k, want_q=True)    # materialises the rows
+        ans_filled = eng.multout(t)
+        check_leading_coefficients(a, b, a_ref, b_ref, name)
+        check_recurrence(O, rp, ci, a, b, Q, name)
+        for j in range(min(k, 6)):                     # early columns: before rounding differences have grown
+            assert np.allclose(Q[j][iso], Q_ref[j][iso], rtol=1e-10, atol=1e-16), (name, j)
+        assert rel_inf(ans_factored, ans_ref) <= REL_INF_TOL, name
+        assert rel_inf(ans_filled, ans_ref) <= REL_INF_TOL, name
+        assert np.allclose(ans_factored, ans_filled, rtol=1e-13, atol=1e-300), name
+        eng.close()
+
+    check(pkg.Engine(0, propagation_blocking=1, hub_entries=256), "blocked")
+    check(pkg.Engine(0, propagation_blocking=0, lazy_normalisation=1), "plain, lazy")
+    check(pkg.Engine(0, propagation_blocking=1, hub_entries=256, isolated_rows=0), "blocked, elementwise")
+    # three ranks: every rank carries the rows of its own slice; their share of ||u||^2 travels in the all-reduce
+    for mode in (dict(propagation_blocking=1, hub_entries=256), dict(propagation_blocking=0)):
+        grp = pkg.LocalGroup([0, 0, 0], **mode)
+        grp.set_graph_csr(rp, ci)
+        a, b, Q, xn, st = grp.lanczos(x0, k)
+        check_leading_coefficients(a, b, a_ref, b_ref, ("local3", mode))
+        check_recurrence(O, rp, ci, a, b, Q, ("local3", mode))
+        for j in range(min(k, 6)):
+            assert np.allclose(Q[j][iso], Q_ref[j][iso], rtol=1e-10, atol=1e-16), (mode, j)
+        assert rel_inf(grp.multout(t), ans_ref) <= REL_INF_TOL, mode
+        grp.close()
+
+
 def test_local_group_matches_single(oracle, pkg):
     """world = 3 handles on one GPU wired as an in-process communicator: same alpha/beta/answer."""
     O = oracle
