@@ -650,7 +650,9 @@ int lzx_graph_prepare(lzx_ctx *c)
         std::vector<u32> perm;
         perm.reserve(c->n_slices);
         c->h_slice_w0.clear();
-        const bool classes = pb && c->narrow_opt != 0;
+        // classes pay from a few slices per wavefront on (each class loop starts with its own descriptor round trips:
+        // on the 1 M-vertex graph, 2.4 slices per wavefront, they cost 1.6 us)
+        const bool classes = pb && c->narrow_opt != 0 && (c->narrow_opt > 0 || c->n_slices >= 8u * (u32)c->cu_count * (LZX_SPMV_BLOCK / 64));
         for (u32 s2 = 0; s2 < c->n_slices; ++s2)
             if (!classes || h_slice_w[s2] > 8) perm.push_back(s2);
         c->ns_wide = (u32)perm.size();
