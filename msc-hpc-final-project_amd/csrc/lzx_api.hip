@@ -122,6 +122,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "spmv_deep")) c->deep_opt = value;
     else if (!strcmp(name, "tie_sort")) c->tie_sort_opt = value;
     else if (!strcmp(name, "pb_group")) c->pb_group_opt = value;
+    else if (!strcmp(name, "pb_group_force")) c->pb_group_force_opt = value;
     else if (!strcmp(name, "item_len")) c->item_opt = value;
     else if (!strcmp(name, "stage_burst")) c->burst_opt = value;
     else if (!strcmp(name, "narrow_slices")) c->narrow_opt = value;

@@ -1856,7 +1856,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         // a band per workgroup is the faster form -- the pass is a handful of round trips long either way
         size_t n_small = 0;
         for (size_t i = 0; i < ni; ++i) n_small += small(i) ? 1 : 0;
-        const size_t per_group = std::min<size_t>(8, n_small / std::max<u32>(1u, c->pb_gather_grid));
+        const size_t per_group = c->pb_group_force_opt > 0 ? 8 : std::min<size_t>(8, n_small / std::max<u32>(1u, c->pb_gather_grid));
         for (size_t i = 0; i < ni;) {
             if (per_group < 2 || !small(i)) {
                 const u32 R = items[4 * i];
