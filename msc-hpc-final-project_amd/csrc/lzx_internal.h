@@ -206,7 +206,7 @@ struct lzx_ctx {
     int64_t deep_opt = -1;             // staged-columns kernel: 1 = four slices in flight instead of two (debug knob; no gain)
     int64_t pb_order_opt = -1;         // kernel order of the blocked SpMV (debug knob): -1/1 scatter, staged columns, gather; 0 staged columns first
     int64_t pb_group_opt = -1;         // values up to which a row band is gathered by ONE wavefront, eight such bands per workgroup item (debug knob; 0 = off)
-    int64_t pb_group_force_opt = -1;   // test hook: eight bands per group whatever the graph's size
+    int64_t pb_group_force_opt = -1;   // test hook: this many bands per group (2 .. 8; 1 = 8) whatever the graph's size
     int64_t pb_gwaves_opt = -1;        // wavefronts per gather workgroup (debug knob): 8 (default) or 4
     u32 pb_gather_block = 512;
     int64_t pb_persist_opt = -1;       // persistent passes: -1/1 on, 0 = one workgroup per unit / static item lists

@@ -26,8 +26,8 @@ MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propag
          dict(propagation_blocking=1, hub_entries=512, pb_reduce=1500, pb_target=1024, pb_unit=4096, pb_column_band=16384),
          # the forms large graphs get by themselves, forced on small ones: narrow staged-only slices class by class, small row
          # bands gathered one wavefront each (eight per item), rows ranked by staged-column count first
-         dict(propagation_blocking=1, hub_entries=64, narrow_slices=1, pb_group_force=1, pb_target=2048),
-         dict(propagation_blocking=1, hub_entries=256, narrow_slices=1, pb_group_force=1, pb_group=1024, tie_sort=2)]
+         dict(propagation_blocking=1, hub_entries=64, narrow_slices=1, pb_group_force=8, pb_target=2048),
+         dict(propagation_blocking=1, hub_entries=256, narrow_slices=1, pb_group_force=8, pb_group=1024, tie_sort=2)]
 
 
 def graphs(O):
