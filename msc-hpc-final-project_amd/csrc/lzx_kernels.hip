@@ -170,21 +170,27 @@ __global__ void __launch_bounds__(LZX_SPMV_BLOCK) k_spmv(const SpmvArgs a)
         } else if (a.world == 1) {
             const u32 pairs = a.hub_real >> 1;               // hub_real is even; x is 16-byte aligned
             const double2 *src = reinterpret_cast<const double2 *>(a.x);
-            for (u32 i0 = 0; i0 < pairs; i0 += 8 * LZX_SPMV_BLOCK) {
-                // clamped index, unconditional load AND store (a store under `if` pulls its load into the branch, and the
-                // eight round trips are serial again); threads past the end rewrite the last pair with its own value
-                double2 t[8];
+            // clamped index, unconditional load AND store (a store under `if` pulls its load into the branch, and the
+            // round trips are serial again); threads past the end rewrite the last pair with its own value
+            auto stage = [&](auto depth_tag) {
+                constexpr u32 D = decltype(depth_tag)::value;   // 16-byte loads per thread in flight
+                for (u32 i0 = 0; i0 < pairs; i0 += D * LZX_SPMV_BLOCK) {
+                    double2 t[D];
 #pragma unroll
-                for (u32 u = 0; u < 8; ++u) {
-                    const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
-                    t[u] = src[i < pairs ? i : pairs - 1];
-                }
+                    for (u32 u = 0; u < D; ++u) {
+                        const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
+                        t[u] = src[i < pairs ? i : pairs - 1];
+                    }
 #pragma unroll
-                for (u32 u = 0; u < 8; ++u) {
-                    const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
-                    reinterpret_cast<double2 *>(hubv)[i < pairs ? i : pairs - 1] = t[u];
+                    for (u32 u = 0; u < D; ++u) {
+                        const u32 i = i0 + tid + u * LZX_SPMV_BLOCK;
+                        reinterpret_cast<double2 *>(hubv)[i < pairs ? i : pairs - 1] = t[u];
+                    }
                 }
-            }
+            };
+            if (a.burst >= 8) stage(std::integral_constant<u32, 8>{});
+            else if (a.burst >= 4) stage(std::integral_constant<u32, 4>{});
+            else stage(std::integral_constant<u32, 2>{});
         } else {
             for (u32 i0 = 0; i0 < a.hub_real; i0 += 8 * LZX_SPMV_BLOCK) {
                 double t[8];
@@ -767,7 +773,7 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     a.world = (u32)c->world;
     a.xs0 = c->xs0;
     a.n_zero = c->pb ? c->n_long64 : 0;
-    a.burst = c->burst_opt > 0 ? 1u : 0u;   // debug knob stage_burst: all loads in flight was 8 us SLOWER (256 CUs hit the same 128 KiB at once), off
+    a.burst = c->burst_opt > 0 ? (u32)c->burst_opt : 0u;   // debug knob stage_burst = loads in flight per thread: the empty kernel takes 9.5 us with one, 8.7 with two, 10.8 with four, 14.5 with eight (256 CUs hit the same 128 KiB at once): off
     a.deep = c->deep_opt > 0 ? 1u : 0u;   // debug knob spmv_deep: no gain measured (DESIGN.md 3.1 g), off
     const bool nt = c->nt_opt > 0;
     // Blocked mode, option "side_stream": the staged-columns kernel and the scatter passes are independent (both only

@@ -64,6 +64,8 @@ if __name__ == "__main__":
         opts = [dict(tie_sort=1), dict(tie_sort=0), dict(tie_sort=2), dict(narrow_slices=0), dict(pb_group=0), dict(tie_sort=1), dict(pb_order=0), dict(tie_sort=2, pb_order=0)]
     if "c2g" in sets:
         opts = [dict(pb_group=0), dict(pb_group_force=2), dict(pb_group_force=4), dict(pb_group_force=8), dict(pb_group=0), dict(pb_group_force=2), dict(pb_group_force=3)]
+    if "bst" in sets:
+        opts = [dict(pb_order=0, stage_burst=b, phase_mask=0) for b in (0, 2, 4, 8, 0, 2)]
     if "grp2" in sets:
         opts = [dict(pb_group=16384), dict(pb_group=0)] * 4
     if "deep" in sets:
