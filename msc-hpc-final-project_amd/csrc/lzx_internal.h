@@ -202,6 +202,7 @@ struct lzx_ctx {
     int64_t pb_stamps_opt = -1;
     int64_t tie_sort_opt = -1;         // blocked mode: ties of the degree ranking broken by staged-column count (debug knob; 0 = by id)
     int64_t item_opt = -1;             // entries per split-row item (debug knob; default LZX_ITEM)
+    int64_t vec_per_cu_opt = -1;       // blocks per CU of the vector kernels (debug knob; default 8)
     int64_t burst_opt = -1;            // staged-columns kernel: staging loads all in flight (debug knob; 0 = one per iteration)
     int64_t deep_opt = -1;             // staged-columns kernel: 1 = four slices in flight instead of two (debug knob; no gain)
     int64_t pb_order_opt = -1;         // kernel order of the blocked SpMV (debug knob): -1/1 scatter, staged columns, gather; 0 staged columns first

@@ -29,8 +29,29 @@ __device__ __forceinline__ double wave_sum(double v)
 // Sum p[0..np) identically in every workgroup of a 256-thread launch. sh: >= 4 doubles of LDS.
 __device__ __forceinline__ double block_sum_fixed_256(const double *p, u32 np, double *sh)
 {
+    // A thread's values are added in index order (the result does not depend on how the loads are scheduled), but they
+    // are FETCHED eight at a time: one load per loop iteration was five dependent round trips for the ~1300 partials of
+    // a blocked SpMV, at the head of every vector kernel (on the 1 M-vertex graph a third of k_lazy_update's 14 us).
     double s = 0.0;
-    for (u32 i = threadIdx.x; i < np; i += LZX_VEC_BLOCK) s += p[i];
+    u32 i = threadIdx.x;
+    for (; i + 7 * LZX_VEC_BLOCK < np; i += 8 * LZX_VEC_BLOCK) {
+        double t[8];
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) t[u] = p[i + u * LZX_VEC_BLOCK];
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) s += t[u];
+    }
+    if (i < np) {   // up to seven more: clamped, unconditional loads
+        double t[7];
+#pragma unroll
+        for (u32 u = 0; u < 7; ++u) {
+            const u32 j = i + u * LZX_VEC_BLOCK;
+            t[u] = p[j < np ? j : i];
+        }
+#pragma unroll
+        for (u32 u = 0; u < 7; ++u)
+            if (i + u * LZX_VEC_BLOCK < np) s += t[u];
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -726,7 +747,9 @@ __global__ void k_iso_fill(double *Q, u32 ldq, u32 k, u32 r0, u32 r1, const doub
 static u32 vec_grid(const lzx_ctx *c)
 {
     const u32 need = (c->n_loc_pad / 2 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
-    const u32 cap = (u32)c->cu_count * 8;
+    // every block first sums the SpMV's ~1300 partials: on a small vector half as many blocks do half as much of that
+    // (1 M rows: 13.5 -> 11.5 us with 4 per CU; 10 M rows: no difference, 2 per CU loses)
+    const u32 cap = (u32)c->cu_count * (c->vec_per_cu_opt > 0 ? (u32)c->vec_per_cu_opt : (c->n_loc_pad <= (4u << 20) ? 4u : 8u));
     return need < 1 ? 1 : (need < cap ? need : cap);
 }
 

@@ -66,6 +66,8 @@ if __name__ == "__main__":
         opts = [dict(pb_group=0), dict(pb_group_force=2), dict(pb_group_force=4), dict(pb_group_force=8), dict(pb_group=0), dict(pb_group_force=2), dict(pb_group_force=3)]
     if "bst" in sets:
         opts = [dict(pb_order=0, stage_burst=b, phase_mask=0) for b in (0, 2, 4, 8, 0, 2)]
+    if "vec" in sets:
+        opts = [dict(vec_blocks_per_cu=v) for v in (8, 4, 2, 1, 8, 4)]
     if "grp2" in sets:
         opts = [dict(pb_group=16384), dict(pb_group=0)] * 4
     if "deep" in sets:
