@@ -128,6 +128,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "vec_blocks_per_cu")) c->vec_per_cu_opt = value;
     else if (!strcmp(name, "narrow_slices")) c->narrow_opt = value;
     else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
+    else if (!strcmp(name, "unnormalised_basis")) c->basis_u_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
@@ -279,6 +280,12 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
             LZX_HIP(hipSetDevice(c->device));
             c->iso_on = lazy && c->iso_opt != 0;
             c->iso_filled = false;
+            c->basis_u = lazy && c->basis_u_opt != 0;
+            // columns 1.. are written by the loop up to rows_live only; with several ranks the exchanged prefix may reach
+            // one slice further (into rows without an edge, which nobody reads): keep that slice clean
+            if (c->basis_u && c->iso_on && k > 1 && c->rows_live < c->n_loc_pad)
+                LZX_HIP(hipMemset2DAsync(c->d_Q + c->ldq + c->rows_live, sizeof(double) * c->ldq, 0,
+                                         sizeof(double) * std::min<u32>(LZX_SLICE, c->n_loc_pad - c->rows_live), k - 1, c->stream));
             if (c->iso_on) LZX_TRY(lzx_launch_iso_prepare(c, k));
         }
     }
@@ -331,7 +338,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         }
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
-            const double *uj = first ? c->d_Q : c->d_u[j & 1];   // u_0 = q_0
+            const double *uj = first ? c->d_Q : (c->basis_u ? c->d_Q + (size_t)j * c->ldq : c->d_u[j & 1]);   // u_0 = q_0
             SpmvLaunch l{multi ? c->d_xbuf : uj, uj, c->d_v, c->d_partials};
             l.live_rows_only = true;   // k_lazy_update below takes (A u)_i = 0 for rows without an edge
             if (overlap && j > 0) l.chunk1_ready = c->ev_c1;
@@ -351,7 +358,12 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         //  the reduction and its all-reduce are billed to the vector work, the exposed part of the all-gather to comm)
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
-            const double *uj = first ? c->d_Q : c->d_u[j & 1];
+            const double *uj = first ? c->d_Q : (c->basis_u ? c->d_Q + (size_t)j * c->ldq : c->d_u[j & 1]);
+            // the resident basis holds u_j (basis_u): nothing normalised is stored, the previous column is divided by
+            // beta_{j-2} on the way in, the next one written in place
+            double *q_store = (first || c->basis_u) ? nullptr : c->d_Q + (size_t)j * c->ldq;
+            double *u_store = last ? nullptr : (c->basis_u ? c->d_Q + (size_t)(j + 1) * c->ldq : c->d_u[(j + 1) & 1]);
+            const double *pdiv = (c->basis_u && j >= 2) ? c->d_beta + (j - 2) : nullptr;
             // one rank: both sums are closed in the kernel's prologue from the partials themselves (no reduce launch);
             // the norm partials alternate between two arrays, the kernel reads one while writing the other
             double *p_out = multi ? c->d_partials2 : ((j & 1) ? c->d_partials3 : c->d_partials2);
@@ -359,12 +371,10 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             if (!multi)
                 LZX_TRY(lzx_launch_lazy_update_local(c, c->d_v, c->rows_live, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_partials,
                                                      lzx_spmv_partials(c), p_in, first ? 0 : c->np2_last, first ? 1 : 0, c->d_alpha + j,
-                                                     first ? nullptr : c->d_beta + (j - 1), first ? nullptr : c->d_Q + (size_t)j * c->ldq,
-                                                     last ? nullptr : c->d_u[(j + 1) & 1], p_out, &np2));
+                                                     first ? nullptr : c->d_beta + (j - 1), q_store, u_store, p_out, &np2, pdiv));
             else
             LZX_TRY(lzx_launch_lazy_update(c, c->d_v, c->rows_live, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_scal + 0, first ? 1 : 0,
-                                           c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), first ? nullptr : c->d_Q + (size_t)j * c->ldq,
-                                           last ? nullptr : c->d_u[(j + 1) & 1], c->d_partials2, &np2));
+                                           c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), q_store, u_store, c->d_partials2, &np2, pdiv));
             c->np2_last = np2;
         }
         LZX_TRY(mk.tick(CAT_VEC));
@@ -372,8 +382,11 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             if (last) break;
             continue;
         }
+        auto next_u = [&](lzx_ctx *c) -> const double * {
+            return c->basis_u ? c->d_Q + (size_t)(j + 1) * c->ldq : c->d_u[(j + 1) & 1];
+        };
         for (size_t i = 0; i < cs.size(); ++i) {
-            src[i] = cs[i]->d_u[(j + 1) & 1];
+            src[i] = next_u(cs[i]);
             dst[i] = cs[i]->d_xbuf;
         }
         if (!overlap) {
@@ -390,11 +403,11 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
                 LZX_HIP(hipEventRecord(c->ev_c0, c->stream2));
             }
             if (c0->sparse) {   // every peer gets only what its rows reference
-                for (size_t i = 0; i < cs.size(); ++i) src[i] = cs[i]->d_u[(j + 1) & 1];
+                for (size_t i = 0; i < cs.size(); ++i) src[i] = next_u(cs[i]);
                 LZX_TRY(lzx_comm_sparse_chunk1(cs, src.data()));
             } else {
                 for (size_t i = 0; i < cs.size(); ++i) {
-                    src[i] = cs[i]->d_u[(j + 1) & 1] + cs[i]->xs0;
+                    src[i] = next_u(cs[i]) + cs[i]->xs0;
                     dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
                 }
                 LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
@@ -579,7 +592,9 @@ static int lanczos_fetch(std::vector<lzx_ctx *> &cs, u32 k, double *alpha, doubl
                 LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->n_loc_pad));
             }
             LZX_HIP(hipSetDevice(c0->device));
-            LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_Q + (size_t)j * c0->ldq, c0->d_io));
+            // columns of the lazy loop hold u_j = beta_{j-1} q_j: the division the loop itself applies, on the way out
+            LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_Q + (size_t)j * c0->ldq, c0->d_io,
+                                           (c0->basis_u && j > 0) ? c0->d_beta + (j - 1) : nullptr));
             LZX_HIP(hipMemcpyAsync(Q + (size_t)j * n, c0->d_io, sizeof(double) * n, hipMemcpyDeviceToHost, c0->stream));
             LZX_TRY(sync_all(cs));
         }
@@ -716,7 +731,7 @@ static int multout_run(std::vector<lzx_ctx *> &cs, const double *t, u32 k, doubl
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
         // the k coefficients are staged in the (idle) block-partials buffer
-        if (k > c->np_cap) LZX_FAIL(LZX_ERR_LIMIT, "k = %u exceeds the staging capacity %u", k, c->np_cap);
+        if (2 * (u64)k > c->np_cap) LZX_FAIL(LZX_ERR_LIMIT, "k = %u exceeds the staging capacity %u", k, c->np_cap / 2);
         LZX_HIP(hipMemcpyAsync(c->d_partials, t, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
         LZX_TRY(lzx_launch_multout(c, c->d_partials, k, c->d_v));
     }

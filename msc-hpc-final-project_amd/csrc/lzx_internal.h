@@ -225,6 +225,11 @@ struct lzx_ctx {
     // Rows without an edge (the tail of every slice, [rows_live, n_loc_pad)) in the lazy loop: (A u)_i = 0 there, so
     // q_j[i] = c_j q_0[i] with ONE scalar recurrence for all of them (k_lazy_update, block 0); the loop neither reads nor
     // writes them, lzx_multout uses the scalars, a host fetch of the basis materialises them first.
+    // Lazy loop: the resident basis holds the UNNORMALISED u_j = beta_{j-1} q_j (column 0: q_0): the loop then reads w, u_j,
+    // u_{j-1} and writes u_{j+1} -- 32 bytes per row instead of 40 -- and q_j = u_j / beta_{j-1} is formed where it is used
+    // (the same division as before: same bits); a fetch divides on the way out, lzx_multout folds 1 / beta into t.
+    bool basis_u = false;
+    int64_t basis_u_opt = -1;          // debug knob unnormalised_basis: 0 = columns hold q_j, u_j alternates between d_u[0 / 1]
     bool iso_on = false;               // the last prepared decomposition runs in that form
     bool iso_filled = false;           // ... and its basis columns 1.. have been materialised for those rows
     double *d_iso = nullptr;           // [2 k_cap + 4]: c_j at [j], d_j (the same for the unnormalised u_j) at [k_cap + 1 + j]; last: sum of q_0[i]^2 over those rows
@@ -284,10 +289,10 @@ int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u
 int lzx_launch_iso_prepare(lzx_ctx *c, u32 k);                       // sum of squares of q_0 over the rows without an edge, c_0 = d_0 = 1
 int lzx_launch_iso_fill(lzx_ctx *c, u32 k);                          // q_j[i] = c_j q_0[i] for those rows, j = 1 .. k - 1
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
-                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out);
+                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr);
 int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,
                                  const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
-                                 double *u_next, double *partials_out, u32 *np_out);
+                                 double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr);
 // v -= alpha q_j (+ beta_prev q_jm1); alpha = sum(partials_in); writes alpha_out; partial ||v||^2 out.
 int lzx_launch_axpy_norm(lzx_ctx *c, double *v, const double *qj, const double *qjm1,
                          const double *partials_in, u32 np_in, double *alpha_out,
@@ -296,7 +301,7 @@ int lzx_launch_axpy_norm(lzx_ctx *c, double *v, const double *qj, const double *
 int lzx_launch_scale(lzx_ctx *c, const double *v, double *q_next, const double *partials_in,
                      u32 np_in, double *beta_out);
 int lzx_launch_permute_in(lzx_ctx *c, const double *io_old_order, double *full, double scale);
-int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io_old_order);
+int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io_old_order, const double *div = nullptr);   // div: device scalar every entry is divided by
 // hand-over layout (stride n_loc_pad) -> exchange layout (stride xs): the active prefix of every rank's slice
 int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_layout);
 int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc);

@@ -536,7 +536,8 @@ k_axpy_norm(double *v, const double *__restrict__ qj, const double *__restrict__
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict__ u, const double *__restrict__ q_prev,
               const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
-              double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n, double *iso, u32 iso_k, u32 iso_j)
+              double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n, double *iso, u32 iso_k, u32 iso_j,
+              const double *prev_div)
 {
     __shared__ double sh[4];
     double D, B;
@@ -570,6 +571,8 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
     }
     double nrm = 0.0;
     const u32 stride = gridDim.x * LZX_VEC_BLOCK * 2;
+    const double bprev = prev_div ? *prev_div : 1.0;
+    if (!q_out && !u_next) n = 0;   // last iteration with the unnormalised basis: only the scalars were wanted
     for (u32 i = (blockIdx.x * LZX_VEC_BLOCK + threadIdx.x) * 2; i < n; i += stride) {
         double2 q = *reinterpret_cast<const double2 *>(u + i);
         if (!first) {
@@ -587,7 +590,11 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
             t.x -= alpha * q.x;
             t.y -= alpha * q.y;
             if (q_prev) {
-                const double2 p = *reinterpret_cast<const double2 *>(q_prev + i);
+                double2 p = *reinterpret_cast<const double2 *>(q_prev + i);
+                if (prev_div) {   // the column holds u_{j-1}: q_{j-1} = u_{j-1} / beta_{j-2}, as it was formed one iteration ago
+                    p.x /= bprev;
+                    p.y /= bprev;
+                }
                 t.x -= beta * p.x;
                 t.y -= beta * p.y;
             }
@@ -684,17 +691,18 @@ __global__ void k_to_f64(const float *in, double *out, u64 count)
     if (i < count) out[i] = (double)in[i];
 }
 
-__global__ void k_permute_out(const double *full, const u32 *gidx, double *io, u64 n)
+__global__ void k_permute_out(const double *full, const u32 *gidx, double *io, u64 n, const double *div)
 {
     const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < n) io[o] = full[gidx[o]];
+    if (o < n) io[o] = div ? full[gidx[o]] / *div : full[gidx[o]];
 }
 
 // ans_loc = Q_loc t: the second dgemv of multOut (parallel-final/lib/multiplyOut.cu:42-44), on the
 // device-resident basis; one thread per row, basis vectors streamed with unit stride.
 // iso != nullptr: rows [rows_act, n) are kept as q_j[i] = iso[j] q_0[i] (lzx_internal.h: iso_on).
+// tq: the coefficients the stored columns are multiplied by (t itself, or t_j / beta_{j-1} when the columns hold u_j).
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
-k_multout(const double *Q, u32 ldq, const double *t, u32 k, double *out, u32 n, u32 rows_act, const double *iso)
+k_multout(const double *Q, u32 ldq, const double *t, const double *tq, u32 k, double *out, u32 n, u32 rows_act, const double *iso)
 {
     const u32 i = blockIdx.x * LZX_VEC_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -703,9 +711,15 @@ k_multout(const double *Q, u32 ldq, const double *t, u32 k, double *out, u32 n, 
         const double z = Q[i];
         for (u32 j = 0; j < k; ++j) s += (j ? iso[j] * z : z) * t[j];
     } else {
-        for (u32 j = 0; j < k; ++j) s += Q[(size_t)j * ldq + i] * t[j];
+        for (u32 j = 0; j < k; ++j) s += Q[(size_t)j * ldq + i] * tq[j];
     }
     out[i] = s;
+}
+
+__global__ void k_multout_coeff(const double *t, const double *beta, u32 k, double *tq)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < k) tq[j] = j ? t[j] / beta[j - 1] : t[j];
 }
 
 // sum of q_0[i]^2 over rows [r0, r1) in two fixed-shape steps (per-block partials, then one block); also c_0 = d_0 = 1
@@ -734,12 +748,12 @@ k_iso_prepare(const double *partials, u32 np, double *iso, u32 iso_k)
 }
 
 // basis columns 1 .. k-1 of the rows without an edge, materialised: q_j[i] = c_j q_0[i]
-__global__ void k_iso_fill(double *Q, u32 ldq, u32 k, u32 r0, u32 r1, const double *iso)
+__global__ void k_iso_fill(double *Q, u32 ldq, u32 k, u32 r0, u32 r1, const double *coeff)
 {
     const u32 i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r1) return;
     const double z = Q[i];
-    for (u32 j = 1; j < k; ++j) Q[(size_t)j * ldq + i] = iso[j] * z;
+    for (u32 j = 1; j < k; ++j) Q[(size_t)j * ldq + i] = coeff[j] * z;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -868,12 +882,13 @@ int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u
 }
 
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
-                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out)
+                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out,
+                           const double *prev_div)
 {
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
                        first, alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha));
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div);
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
@@ -881,12 +896,12 @@ int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double
 
 int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,
                                  const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
-                                 double *u_next, double *partials_out, u32 *np_out)
+                                 double *u_next, double *partials_out, u32 *np_out, const double *prev_div)
 {
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, nullptr, pa, na, pb, nb, first,
                        alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha));
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div);
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
@@ -922,11 +937,11 @@ int lzx_launch_permute_in(lzx_ctx *c, const double *io, double *full, double div
     return LZX_OK;
 }
 
-int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io)
+int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io, const double *div)
 {
     if (c->n == 0) return LZX_OK;
     const u32 g = (u32)((c->n + 255) / 256);
-    hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, c->stream, full, c->d_gidx_of_old, io, c->n);
+    hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, c->stream, full, c->d_gidx_of_old, io, c->n, div);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }
@@ -973,7 +988,12 @@ int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc)
 {
     const u32 g = (c->n_loc_pad + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
     const bool factored = c->iso_on && !c->iso_filled;
-    hipLaunchKernelGGL(k_multout, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Q, c->ldq, t_dev, k,
+    const double *tq = t_dev;
+    if (c->basis_u) {   // the caller left room for k more doubles behind t
+        hipLaunchKernelGGL(k_multout_coeff, dim3((k + 255) / 256), dim3(256), 0, c->stream, t_dev, c->d_beta, k, const_cast<double *>(t_dev) + k);
+        tq = t_dev + k;
+    }
+    hipLaunchKernelGGL(k_multout, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Q, c->ldq, t_dev, tq, k,
                        out_loc, c->n_loc_pad, c->rows_live, factored ? c->d_iso : nullptr);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
@@ -1000,7 +1020,8 @@ int lzx_launch_iso_fill(lzx_ctx *c, u32 k)
 {
     if (k > 1 && c->n_loc_pad > c->rows_live) {
         const u32 rows = c->n_loc_pad - c->rows_live;
-        hipLaunchKernelGGL(k_iso_fill, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Q, c->ldq, k, c->rows_live, c->n_loc_pad, c->d_iso);
+        hipLaunchKernelGGL(k_iso_fill, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Q, c->ldq, k, c->rows_live, c->n_loc_pad,
+                           c->basis_u ? c->d_iso + c->iso_cap + 1 : c->d_iso);   // d_j where the columns hold u_j, c_j otherwise
         LZX_HIP(hipGetLastError());
     }
     return LZX_OK;

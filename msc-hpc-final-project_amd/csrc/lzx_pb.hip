@@ -1559,16 +1559,19 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     //      (Option pb_reduce = 0, everything plain: closed at ~target entries instead, one gather item per band.)
     const bool reduce = c->pb_reduce_opt != 0;
     const u32 min_run = !reduce ? 0xffffffffu : c->pb_reduce_opt > 1 ? (u32)c->pb_reduce_opt : LZX_PBR_MIN_RUN;
+    // bands cover the rows that can have entries: rows without an edge (the tail behind rows_live) belong to no band --
+    // the gather pass must not touch them (the lazy loop keeps neither v nor the basis columns there)
+    const u32 band_rows = std::min(c->n_loc_real, c->rows_live);
     std::vector<u32> row0;
     row0.push_back(0);
     if (reduce) {
         u32 l = 0;
-        while (l < c->n_loc_real) {
+        while (l < band_rows) {
             // replicas for the band's heaviest row (rows are ranked by degree or by staged-column count: the blocked
             // count falls only roughly along the order)
             u32 rep = 1;
             for (;;) {
-                const u32 e = (u32)std::min<u64>((u64)l + LZX_PB_RB / rep, c->n_loc_real);
+                const u32 e = (u32)std::min<u64>((u64)l + LZX_PB_RB / rep, band_rows);
                 u32 heaviest = 0;
                 for (u32 j = l; j < e; ++j) heaviest = std::max(heaviest, h_nh[j]);
                 u32 need = rep;
@@ -1576,13 +1579,13 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
                 if (need == rep) break;
                 rep = need;
             }
-            l = (u32)std::min<u64>((u64)l + LZX_PB_RB / rep, c->n_loc_real);
+            l = (u32)std::min<u64>((u64)l + LZX_PB_RB / rep, band_rows);
             row0.push_back(l);
         }
     } else {
         u32 rows = 0;
         u64 cnt = 0;
-        for (u32 l = 0; l < c->n_loc_real; ++l) {
+        for (u32 l = 0; l < band_rows; ++l) {
             const u32 nh = h_nh[l];
             if (rows > 0 && (cnt + nh > target || rows == LZX_PB_RB)) {
                 row0.push_back(l);
@@ -1592,9 +1595,9 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             ++rows;
             cnt += nh;
         }
-        if (rows > 0) row0.push_back(c->n_loc_real);
+        if (rows > 0) row0.push_back(band_rows);
     }
-    if (row0.size() == 1) row0.push_back(c->n_loc_real);
+    if (row0.size() == 1) row0.push_back(band_rows);
     const u32 nr = (u32)row0.size() - 1;
     if (nr >= (1u << 24)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u row bands (limit 2^24)", nr);
     LZX_TRY(pb_alloc(&c->d_pb_row0, (u64)nr + 1));
