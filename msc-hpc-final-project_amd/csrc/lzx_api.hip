@@ -127,6 +127,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "stage_burst")) c->burst_opt = value;
     else if (!strcmp(name, "vec_blocks_per_cu")) c->vec_per_cu_opt = value;
     else if (!strcmp(name, "narrow_slices")) c->narrow_opt = value;
+    else if (!strcmp(name, "fuse_staged")) c->fuse_opt = value;
     else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
     else if (!strcmp(name, "unnormalised_basis")) c->basis_u_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;

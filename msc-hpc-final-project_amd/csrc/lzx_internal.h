@@ -158,6 +158,7 @@ struct lzx_ctx {
     u32 *d_slice_perm = nullptr;       // [n_slices] slice ids: wide ones (> 8 codes) in order, then width 8, width 4, width 0
     u32 ns_wide = 0, ns_w8 = 0, ns_w4 = 0;
     std::vector<u32> h_slice_w0;       // ids of the width-0 slices, ascending (their live prefix is counted per launch)
+    int64_t fuse_opt = -1;             // debug knob fuse_staged: 0 = staged-columns kernel in its own launch, 1 = fused behind the scatter units (default: ahead of them)
     int64_t narrow_opt = -1;           // debug knob narrow_slices: 0 = every slice through the general loop
     bool codes16 = false;              // staged-only tables (propagation-blocking mode): 16-bit codes
     u32 *d_sell_cols = nullptr;
@@ -269,8 +270,9 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
 void lzx_pb_release(lzx_ctx *c);
 // chunk1_ready (may be null): event after which the second chunk of the exchange layout is valid in x
 // phases: 1 = scatter pass, 2 = gather (+ finish) pass, 3 = both
+struct SpmvArgs;   // lzx_spmv_body.h
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
-                  hipEvent_t v_ready, int phases = 3);
+                  hipEvent_t v_ready, int phases = 3, const struct SpmvArgs *fuse = nullptr, u32 fuse_blocks = 0, bool *fused = nullptr);
 u32 lzx_pb_partials(const lzx_ctx *c);
 
 // ---- lzx_kernels.hip ----

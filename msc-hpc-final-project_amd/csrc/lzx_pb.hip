@@ -39,6 +39,7 @@
 #include <utility>
 
 #include "lzx_internal.h"
+#include "lzx_spmv_body.h"
 
 namespace {
 
@@ -353,14 +354,14 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 //       contiguous loads, and 32-byte-per-lane stores that are contiguous inside a run; 4 quads per lane in flight.
 // DBG: the LZX_ABLATE experiment switches behind DESIGN.md's ablation numbers are compiled in (slower even when 0).
 template <u32 CB, bool DBG>
-__global__ void __launch_bounds__(1024)
-k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
-             const double *__restrict__ x, u64 xlen, double *val, int ablate_arg)
+__device__ __forceinline__ void
+pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
+                const double *__restrict__ x, u64 xlen, double *val, int ablate_arg, const u32 ublock)
 {
     const int ablate = DBG ? ablate_arg : 0;
     const bool ab_store = ablate == 6 || ablate == 9, ab_lds = ablate == 7 || ablate == 9, ab_carry = ablate == 8 || ablate == 9;
     extern __shared__ __attribute__((aligned(16))) double tile[];   // CB staged values + a zero for padding
-    const u32 band = unit[5 * blockIdx.x];
+    const u32 band = unit[5 * ublock];
     const u64 base = (u64)band * CB;
     // staging is dead time for this CU (the tile leaves room for one workgroup): all eight 16-byte loads of a
     // thread are issued before the first LDS write, so it costs one memory round trip
@@ -401,7 +402,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
     constexpr u32 W = 1024 / 64;
 
     {   // ---- reduced bands
-        const u32 beg = unit[5 * blockIdx.x + 1], end = unit[5 * blockIdx.x + 2];
+        const u32 beg = unit[5 * ublock + 1], end = unit[5 * ublock + 2];
         // A row whose entries span several lanes is summed across them through 65 wave-private LDS slots: every lane
         // adds what follows its last piece end (its whole sum if it has none) to the slot named after the last lane
         // before it that holds a piece end; the lane holding the row's end starts its running sum from that slot.
@@ -463,7 +464,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
     }
 
     {   // ---- plain bands
-        const u32 beg = unit[5 * blockIdx.x + 3], end = unit[5 * blockIdx.x + 4];
+        const u32 beg = unit[5 * ublock + 3], end = unit[5 * ublock + 4];
         // wavefront w takes the unit's 256-quad blocks w, w + 16, ...: the workgroup reads one stream and its writes
         // move through the value array together
         for (u32 blk = beg + wv * 256u; blk < end; blk += W * 256u) {
@@ -507,6 +508,36 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
         }
         }
     }
+}
+
+template <u32 CB, bool DBG>
+__global__ void __launch_bounds__(1024)
+k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
+             const double *__restrict__ x, u64 xlen, double *val, int ablate_arg)
+{
+    pb_scatter_body<CB, DBG>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, ablate_arg, blockIdx.x);
+}
+
+// Scatter pass and staged-columns kernel in ONE launch (single GPU, 16 Ki bands): the persistent workgroups of the
+// staged-columns kernel (lzx_spmv_body.h) and the scatter units share a grid.  Both only read x and write different things
+// (v / values), one workgroup of either kind fits a CU, and workgroups are dispatched in index order.  spmv_first (the
+// default): the 256 staged-columns workgroups start on every CU at once and the scatter units follow as CUs come free, so
+// the launch ends with the small tapered units instead of a second ramp and drain; the other order (debug knob
+// fuse_staged = 1: staged columns behind the units, filling the scatter pass's tail while the write-back of its values
+// drains in their shadow) measures the same.  C3: SpMV 0.616 -> 0.601 ms against separate launches.
+template <u32 CB>
+__global__ void __launch_bounds__(1024)
+k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
+                  const double *__restrict__ x, u64 xlen, double *val, const SpmvArgs a, const u32 spmv_first)
+{
+    const u32 spmv_blocks = gridDim.x - n_units;
+    if (spmv_first) {
+        if (blockIdx.x < spmv_blocks) spmv_body<2, false>(a, blockIdx.x, spmv_blocks);
+        else pb_scatter_body<CB, false>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, 0, blockIdx.x - spmv_blocks);
+        return;
+    }
+    if (blockIdx.x < n_units) pb_scatter_body<CB, false>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, 0, blockIdx.x);
+    else spmv_body<2, false>(a, blockIdx.x - n_units, spmv_blocks);
 }
 
 __device__ __forceinline__ double wave_sum_pb(double v)
@@ -2004,8 +2035,9 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
 }
 
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
-                  hipEvent_t v_ready, int phases)
+                  hipEvent_t v_ready, int phases, const SpmvArgs *fuse, u32 fuse_blocks, bool *fused)
 {
+    if (fused) *fused = false;
     const bool do_scatter = phases & 1, do_gather = phases & 2;
     if (!c->pb) {
         // no blocked tables on this rank: still order the stream behind the second chunk of the exchange, so that the next
@@ -2062,6 +2094,16 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
             return;
         }
 #endif
+        if (fuse && fused && !ablate && c->pb_cb == LZX_PB_CB && u0 == 0 && u1 == c->pb_units) {
+            // the staged-columns workgroups ride behind the scatter units of the same launch (k_pb_scatter_spmv)
+            auto kf = k_pb_scatter_spmv<LZX_PB_CB>;
+            const size_t ldsf = std::max(lds1, c->spmv_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            hipLaunchKernelGGL(kf, dim3(u1 + fuse_blocks), dim3(1024), ldsf, c->stream, c->d_pb_unit, u1, c->d_pbr_code, c->d_pbr_base,
+                               reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val, *fuse, c->fuse_opt == 1 ? 0u : 1u);
+            *fused = true;
+            return;
+        }
         hipLaunchKernelGGL(kern, dim3(u1 - u0), dim3(1024), lds1, c->stream, c->d_pb_unit + 5 * (size_t)u0, c->d_pbr_code,
                            c->d_pbr_base, reinterpret_cast<const uint2 *>(c->d_pb_lcol), c->d_pb_dst, x, c->xlen, c->d_pb_val, ablate);
     };
