@@ -1562,7 +1562,11 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     if (total >= LZX_PB_SLOT_LIMIT) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %llu entries do not fit 32-bit slots", (unsigned long long)total);
     // column band = LDS tile of x: 16 Ki values; 8 Ki (two scatter workgroups per CU, more and shorter units) when x sits
     // in the L2s anyway (C2: scatter 0.033 -> 0.024 ms; on C3 the doubled number of (row, band) pairs loses: 0.75 -> 0.87 ms)
-    c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384) ? (u32)c->pb_cb_opt : (c->xlen * sizeof(double) <= (16u << 20) ? 8192u : LZX_PB_CB);
+    // (that was for a scatter pass with a launch of its own: sharing one with the staged-columns kernel, whose 128 KiB tile
+    //  leaves room for one workgroup per CU either way, 16 Ki bands win there too -- C2 SpMV 0.076 -> 0.068 ms; 8 Ki bands
+    //  remain for the two-chunk exchange on several ranks, where the passes are launched separately)
+    c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384) ? (u32)c->pb_cb_opt
+               : (c->xlen * sizeof(double) <= (16u << 20) && (c->overlap || c->fuse_opt == 0) ? 8192u : LZX_PB_CB);
     const u32 nb = (u32)((c->xlen + c->pb_cb - 1) / c->pb_cb);
     if (nb >= (1u << 16)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u column bands (limit 65535)", nb);
     // values per gather item / entries per plain band: every wavefront slot of the gather pass (2 workgroups of 8 per
@@ -2094,9 +2098,9 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
             return;
         }
 #endif
-        if (fuse && fused && !ablate && c->pb_cb == LZX_PB_CB && u0 == 0 && u1 == c->pb_units) {
-            // the staged-columns workgroups ride behind the scatter units of the same launch (k_pb_scatter_spmv)
-            auto kf = k_pb_scatter_spmv<LZX_PB_CB>;
+        if (fuse && fused && !ablate && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192) && u0 == 0 && u1 == c->pb_units) {
+            // the staged-columns workgroups share the launch of the scatter units (k_pb_scatter_spmv)
+            auto kf = c->pb_cb == 8192 ? k_pb_scatter_spmv<8192> : k_pb_scatter_spmv<LZX_PB_CB>;
             const size_t ldsf = std::max(lds1, c->spmv_lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             hipLaunchKernelGGL(kf, dim3(u1 + fuse_blocks), dim3(1024), ldsf, c->stream, c->d_pb_unit, u1, c->d_pbr_code, c->d_pbr_base,

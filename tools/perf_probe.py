@@ -70,6 +70,8 @@ if __name__ == "__main__":
         opts = [dict(vec_blocks_per_cu=v) for v in (8, 4, 2, 1, 8, 4)]
     if "fuse" in sets:
         opts = [dict(fuse_staged=1), dict(fuse_staged=2), dict(fuse_staged=0)] * 4
+    if "fuse2" in sets:
+        opts = [dict(fuse_staged=2), dict(fuse_staged=2, pb_column_band=16384), dict(fuse_staged=1), dict(fuse_staged=0)] * 2
     if "grp2" in sets:
         opts = [dict(pb_group=16384), dict(pb_group=0)] * 4
     if "deep" in sets:
