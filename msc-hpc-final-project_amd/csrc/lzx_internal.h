@@ -271,6 +271,7 @@ void lzx_pb_release(lzx_ctx *c);
 // chunk1_ready (may be null): event after which the second chunk of the exchange layout is valid in x
 // phases: 1 = scatter pass, 2 = gather (+ finish) pass, 3 = both
 struct SpmvArgs;   // lzx_spmv_body.h
+bool lzx_pb_can_fuse(const lzx_ctx *c);
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
                   hipEvent_t v_ready, int phases = 3, const struct SpmvArgs *fuse = nullptr, u32 fuse_blocks = 0, bool *fused = nullptr);
 u32 lzx_pb_partials(const lzx_ctx *c);

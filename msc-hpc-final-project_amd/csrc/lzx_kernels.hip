@@ -428,10 +428,24 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
         hs = c->stream3;
     }
     bool fused = false;
+    // two-chunk exchange: the staged-columns workgroups share the launch of the chunk-0 scatter units (they come first in
+    // that grid, as the kernel of its own did); the rest of the scatter pass follows once chunk 1 has arrived
+    const bool fuse_chunked = c->pb && !side && l.chunk1_ready && c->codes16 && !nt && !c->trace && c->fuse_opt != 0 && c->fuse_opt != 1 &&
+                              lzx_pb_can_fuse(c);
+    if (fuse_chunked) {
+        LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, pb_partials, l.chunk1_ready, nullptr, 3, &a, c->spmv_grid, &fused));
+        if (fused) {
+            LZX_HIP(hipGetLastError());
+            return LZX_OK;
+        }
+        // (not fused after all -- a debug form of the scatter pass: the passes ran without the staged-columns kernel, which
+        //  cannot happen in the product library; fall through would double the passes, so this is an error)
+        LZX_FAIL(LZX_ERR_STATE, "fused launch was refused");
+    }
     if (scatter_first) {
         if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[2], c->stream));
         // the staged-columns workgroups in the scatter pass's launch, behind its units (lzx_pb.hip: k_pb_scatter_spmv)
-        const bool fuse = c->codes16 && !nt && !c->trace && c->fuse_opt != 0;
+        const bool fuse = c->codes16 && !nt && !c->trace && c->fuse_opt != 0 && lzx_pb_can_fuse(c);
         LZX_TRY(lzx_pb_launch(c, l.x, l.q_loc, l.v, pb_partials, l.chunk1_ready, nullptr, 1, fuse ? &a : nullptr, c->spmv_grid, &fused));
     }
     if (c->trace) LZX_HIP(hipEventRecord(c->trace_ev[0], c->stream));

@@ -2038,6 +2038,16 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
     return rc;
 }
 
+// can the staged-columns workgroups share the scatter pass's launch?  (not with the experimental forms of the pass)
+bool lzx_pb_can_fuse(const lzx_ctx *c)
+{
+    if (!c->pb || !(c->pb_cb == LZX_PB_CB || c->pb_cb == 8192)) return false;
+#ifdef LZX_DEBUG_KNOBS
+    if (c->pb_persist_opt > 0 || getenv("LZX_ABLATE") || (c->phase_mask_opt & (4 | 8))) return false;
+#endif
+    return true;
+}
+
 int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, double *partials, hipEvent_t chunk1_ready,
                   hipEvent_t v_ready, int phases, const SpmvArgs *fuse, u32 fuse_blocks, bool *fused)
 {
@@ -2073,8 +2083,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     if (c->pb_units && fixed)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1p));
 #endif
-    auto scatter = [&](u32 u0, u32 u1) {
-        if (u1 <= u0) return;
+    auto scatter = [&](u32 u0, u32 u1, bool may_fuse) {
+        if (u1 <= u0 && !(may_fuse && fuse && fused)) return;
 #ifdef LZX_DEBUG_KNOBS
         if (fixed) {
             // schedule 0 = the bands of chunk 0 (units [0, pb_units0)), schedule 1 = the rest; a call for all units runs both
@@ -2098,7 +2108,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
             return;
         }
 #endif
-        if (fuse && fused && !ablate && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192) && u0 == 0 && u1 == c->pb_units) {
+        if (may_fuse && fuse && fused && !ablate && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192) && u0 == 0) {
             // the staged-columns workgroups share the launch of the scatter units (k_pb_scatter_spmv)
             auto kf = c->pb_cb == 8192 ? k_pb_scatter_spmv<8192> : k_pb_scatter_spmv<LZX_PB_CB>;
             const size_t ldsf = std::max(lds1, c->spmv_lds);
@@ -2115,11 +2125,11 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     if ((c->phase_mask_opt & 4) || !do_scatter) {
         // experiment: gather pass alone (reads values a previous SpMV left); or the scatter pass was launched earlier
     } else if (chunk1_ready) {
-        scatter(0, c->pb_units0);
+        scatter(0, c->pb_units0, true);    // with the staged-columns workgroups ahead of the chunk-0 units when the caller asks
         LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
-        scatter(c->pb_units0, c->pb_units);
+        scatter(c->pb_units0, c->pb_units, false);
     } else {
-        scatter(0, c->pb_units);
+        scatter(0, c->pb_units, true);
     }
     if (c->trace && do_scatter) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
     if (!do_gather) {
