@@ -72,6 +72,8 @@ if __name__ == "__main__":
         opts = [dict(fuse_staged=1), dict(fuse_staged=2), dict(fuse_staged=0)] * 4
     if "fuse2" in sets:
         opts = [dict(fuse_staged=2), dict(fuse_staged=2, pb_column_band=16384), dict(fuse_staged=1), dict(fuse_staged=0)] * 2
+    if "unit2" in sets:
+        opts = [dict(pb_unit=131072), dict(pb_unit=65536), dict(pb_unit=98304), dict(pb_unit=196608), dict(pb_unit=131072, pb_taper=0), dict(pb_unit=131072)]
     if "grp2" in sets:
         opts = [dict(pb_group=16384), dict(pb_group=0)] * 4
     if "deep" in sets:
