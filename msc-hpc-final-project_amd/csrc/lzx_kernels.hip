@@ -413,12 +413,14 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &l)
     // which adds into the v it wrote, waits for it.  Measured: C3 +1..2 %, C2 -4 % (two more event operations per
     // SpMV) -- off by default.
     const bool side = c->pb && c->side_opt > 0 && !c->trace;
-    // Blocked mode: the scatter pass goes FIRST, the staged-columns kernel between it and the gather pass.  The gather
-    // pass reads the 0.6 GB of values the scatter pass has just written; straight behind it, it competes with the
-    // write-back of the quarter of them still dirty in the Infinity Cache (gather alone 0.21 ms, behind the scatter
-    // 0.25 ms on C3).  The staged-columns kernel in between is bound by round trips, not by bandwidth: the write-back
-    // drains in its shadow.  Both only read x, and the gather pass adds into the v that kernel wrote.
-    // (not with the two-chunk exchange: there the staged-columns kernel runs first, while chunk 1 is still on the wire)
+    // Blocked mode.  The scatter pass and the staged-columns kernel both only read x and write different things; the
+    // gather pass adds into the v the latter wrote and reads the values the former wrote.  Product form: the two share ONE
+    // launch (lzx_pb.hip: k_pb_scatter_spmv; with the two-chunk exchange: the staged-columns workgroups + the chunk-0
+    // units, then the rest of the scatter pass once chunk 1 has arrived).  With launches of their own (debug knobs
+    // fuse_staged = 0, tracing, non-temporal loads) the scatter pass goes first and the staged-columns kernel between it
+    // and the gather pass: the gather pass reads 0.6 GB of values just written and, straight behind the scatter pass,
+    // competes with the write-back of those still dirty in the Infinity Cache (0.25 instead of 0.21 ms on C3); the
+    // staged-columns kernel in between lets that write-back drain in its shadow.
     const bool scatter_first = c->pb && !side && c->pb_order_opt != 0 && !l.chunk1_ready;
     double *pb_partials = l.partials + c->spmv_grid + (c->pb ? 0 : c->fin_grid);
     hipStream_t hs = c->stream;
