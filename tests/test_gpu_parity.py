@@ -429,3 +429,60 @@ def test_general_csr_patterns(oracle, engine_factory):
         eng.set_graph_csr(rp, ci)
         assert np.allclose(eng.spmv(x), y_ref, rtol=1e-12, atol=1e-12), mode
         eng.close()
+
+
+def test_odd_shapes_through_the_large_graph_forms(oracle, pkg):
+    """Small graphs of awkward shapes -- no vertex without an edge, almost none with one, fewer vertices than a slice, a
+    star, a clique beside isolated vertices, more staged slots than vertices -- through the forms large graphs take by
+    themselves (narrow slice classes, grouped gather bands, shared scatter / staged-columns launch, unnormalised basis,
+    rows without an edge as a scalar recurrence), on one handle and on three: SpMV of a random vector against the oracle
+    at 1e-13, the recurrence of every basis column, the overflow-safe centrality functional at 1e-10."""
+    O = oracle
+    rng = np.random.default_rng(2024)
+
+    def sym(n, src, dst):
+        keep = src != dst
+        src, dst = src[keep].astype(np.uint64), dst[keep].astype(np.uint64)
+        return O.csr_from_keys(n, np.concatenate([(src << np.uint64(32)) | dst, (dst << np.uint64(32)) | src]))
+
+    shapes = {}
+    n = 5000
+    ring = np.arange(n)
+    shapes["ring + chords (every vertex has an edge)"] = sym(n, np.concatenate([ring, rng.integers(0, n, 20000)]),
+                                                             np.concatenate([(ring + 1) % n, rng.integers(0, n, 20000)]))
+    n = 40000
+    shapes["three edges among 40 000 vertices"] = sym(n, np.array([5, 17, 39999]), np.array([6, 39998, 0]))
+    shapes["40 vertices"] = sym(40, rng.integers(0, 40, 200), rng.integers(0, 40, 200))
+    n = 30000
+    shapes["star"] = sym(n, np.zeros(n - 1, dtype=np.int64), np.arange(1, n))
+    k60 = np.array([(i, j) for i in range(60) for j in range(i + 1, 60)])
+    shapes["clique of 60 beside 20 000 isolated vertices"] = sym(20060, k60[:, 0] + 10000, k60[:, 1] + 10000)
+    n = 9000
+    shapes["skewed, 9 000 vertices"] = O.gen_rmat(14, n, 150000, 3, a=0.65, b=0.15, c=0.15)
+    modes = (dict(propagation_blocking=1, hub_entries=64, narrow_slices=1, pb_group_force=8, pb_target=2048),
+             dict(propagation_blocking=1, hub_entries=16384, narrow_slices=1, pb_group_force=2),
+             dict(propagation_blocking=1, hub_entries=32, fuse_staged=1, tie_sort=2),
+             dict(propagation_blocking=1, hub_entries=32, fuse_staged=0, unnormalised_basis=0))
+    for name, (rp, ci) in shapes.items():
+        n = len(rp) - 1
+        k = min(12, n - 1)
+        x0 = 0.5 + rng.random(n)
+        x = rng.random(n)
+        y_ref = O.spmv(rp, ci, x)
+        a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, x0, q_colmajor=True)
+        ref = shift_weights(O, a_ref, b_ref, xn_ref) @ Q_ref
+        for mode in modes:
+            for world in (1, 3):
+                eng = pkg.Engine(0, **mode) if world == 1 else pkg.LocalGroup([0] * world, **mode)
+                eng.set_graph_csr(rp, ci)
+                assert np.allclose(eng.spmv(x), y_ref, rtol=1e-13, atol=0), (name, mode, world)
+                a, b, Q, xn, st = eng.lanczos(x0, k)
+                assert xn == xn_ref and np.isfinite(a).all() and np.isfinite(b).all(), (name, mode, world)
+                # a Krylov space that closes early (star, clique: three or two distinct eigen-directions) ends in 0 / 0: only the
+                # columns before the breakdown are defined -- in the oracle as well
+                good = int(np.argmax(b_ref < 1e-9 * np.abs(a_ref).max())) if (b_ref < 1e-9 * np.abs(a_ref).max()).any() else k - 1
+                check_leading_coefficients(a, b, a_ref, b_ref, (name, mode, world))
+                if good >= k - 1:
+                    check_recurrence(O, rp, ci, a, b, Q, (name, mode, world))
+                    assert rel_inf(eng.multout(shift_weights(O, a, b, xn)), ref) <= REL_INF_TOL, (name, mode, world)
+                eng.close()
