@@ -288,9 +288,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_spmv (staged columns from LDS) + k_pb_scatter + k_pb_gather (+ k_long_finish, k_pb_finish): "
-                           "propagation-blocked CSR SpMV (partial row sums cross the two passes) fused with the alpha "
-                           "partial") if gi["pb_entries"] else
+                "kernel": ("k_pb_scatter_spmv (scatter pass + staged columns from LDS, one launch; k_spmv + k_pb_scatter when they "
+                           "are launched separately) + k_pb_gather + k_pb_finish: propagation-blocked CSR SpMV (partial row "
+                           "sums cross the two passes) fused with the alpha partial") if gi["pb_entries"] else
                           "k_spmv (+ k_long_finish): CSR SpMV fused with the alpha partial",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS * world,
