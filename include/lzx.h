@@ -162,6 +162,19 @@ int lzx_lanczos_prepare_f64(lzx_handle h, const double *x0, uint32_t k, double *
 int lzx_lanczos_run(lzx_handle h, lzx_stats *stats);
 int lzx_lanczos_fetch_f64(lzx_handle h, uint32_t k, double *alpha, double *beta, double *Q);
 int lzx_lanczos_fetch_f64_local(lzx_handle *hs, int world, uint32_t k, double *alpha, double *beta, double *Q);
+/* The same loop in chunks (the reference's open problem of choosing k: parallel-final/lib/
+ * multiplyOut.cu:25-49 can only evaluate a decomposition that has already run all its iterations; writeup section 11).
+ * After lzx_lanczos_prepare_f64(h, x0, k_max, ..) each call runs up to `steps` more iterations of the SAME decomposition
+ * -- every piece of loop state lives in HBM, so k iterations in chunks give the bits of k iterations in one go -- and
+ * after every call alpha / beta / the basis of the iterations done so far can be used (lzx_lanczos_fetch_f64,
+ * lzx_multout_f64, lzx_multout_change_f64 with k <= done), so that a caller who sees its answer converge stops paying for
+ * SpMVs.  lzx_lanczos_run == run_steps(all that is left).  lzx_spmv_f64 / lzx_bench_spmv between two chunks void the
+ * prepared state (LZX_ERR_STATE on the next chunk); lzx_multout* and lzx_lanczos_fetch* do not.
+ * lzx_lanczos_progress: iterations done / prepared (prepared == 0: nothing to resume).                            */
+int lzx_lanczos_run_steps(lzx_handle h, uint32_t steps, lzx_stats *stats);
+int lzx_lanczos_run_steps_local(lzx_handle *hs, int world, uint32_t steps, lzx_stats *stats);
+int lzx_lanczos_prepare_f64_local(lzx_handle *hs, int world, const double *x0, uint32_t k, double *x_norm);
+int lzx_lanczos_progress(lzx_handle h, uint32_t *done, uint32_t *prepared);
 /* Wait for everything queued on the handle's stream. */
 int lzx_sync(lzx_handle h);
 /* The same over `world` handles wired with lzx_comm_init_local, driven by one host thread. */
@@ -175,6 +188,12 @@ int lzx_lanczos_f64_local(lzx_handle *hs, int world, const double *x0, uint32_t 
 int lzx_multout_f64(lzx_handle h, const double *t, uint32_t k, double *ans);
 int lzx_multout_f64_local(lzx_handle *hs, int world, const double *t, uint32_t k, double *ans);
 
+/* Convergence monitor without the n-vector crossing PCIe: y_k = Q_k t is formed on the device as in lzx_multout_f64 and
+ * kept there; *rel_change = ||y_k - y_prev||_2 / ||y_k||_2 against the answer of the previous call since the last
+ * prepare (1.0 for the first call).  The host-side stopping rule of multOutAdaptive (host/multiplyOut.cc) on two scalars. */
+int lzx_multout_change_f64(lzx_handle h, const double *t, uint32_t k, double *rel_change);
+int lzx_multout_change_f64_local(lzx_handle *hs, int world, const double *t, uint32_t k, double *rel_change);
+
 /* ---- measurement hook --------------------------------------------------------------------------
  * Runs `reps` back-to-back SpMVs of the current graph on a device-resident vector and returns the
  * average and minimum HIP-event time of one SpMV (all its kernels) in milliseconds.              */
@@ -185,7 +204,7 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  * bytes (rounded to 16; >= 256 MiB recommended), best of `reps`.  Results in GB/s (copy: bytes read + bytes written). */
 int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_gbs, double *copy_gbs);
 
-/* Tuning knobs, to be set before the graph is handed over:
+/* Options, to be set before the graph is handed over (the last two: any time no decomposition is in progress):
  *   "hub_entries"           x values of the highest-degree vertices staged in LDS by the SpMV (0 = none)
  *   "propagation_blocking"  1 / 0 force the two-pass blocked treatment of non-staged columns on / off
  *                           (default: on for graphs whose x does not fit the L2s); with it off the sliced-ELL
@@ -202,9 +221,27 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *   "lazy_normalisation"    1: multiply (and, with several ranks, exchange) the unnormalised vector, so that alpha and
  *                           beta come out of one reduction per iteration (one 2-double all-reduce) and one vector kernel;
  *                           0: the reference's operation order.  Default: 1 with several ranks and in blocked mode, 0 on
- *                           one GPU in plain mode
+ *                           one GPU in plain mode.
+ *                           NB with it on, alpha_j = D / B is formed from the sums over the UNNORMALISED vector -- not the
+ *                           reference's operation order (serial/lib/lanczos.cc:26: alpha_j = <A q_j, q_j>); same recurrence,
+ *                           operands rounded at other places, covered at 1e-10 on the fixtures (tests/test_gpu_parity.py)
  *   "timing_marks_every"    iterations between the HIP-event timing marks behind lzx_stats (default 4; 1 = every iteration)
- * These seven are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
+ *   "reorthogonalise"       e > 0: the Arnoldi pass of serial/lib/lanczos.cc:58-132 (decompose_with_arnoldi): when j % e == 0
+ *                           and j > 2, A q_j is orthogonalised against q_0 .. q_{j-2} (modified Gram-Schmidt in the
+ *                           reference's order, one launch per basis vector) before alpha_j is taken.  The reference
+ *                           hard-codes e = 2 (:71) -- which lets orthogonality go between two passes and then removes
+ *                           components T does not record: "neither give good results", serial/tests/numerical_test_orthog.cc:3-4,
+ *                           and on BASELINE C2 at k = 50 it is off by O(1) -- e = 1 keeps the basis orthogonal (C2, k = 50:
+ *                           1e-11 from the extended-precision referee where the plain loop is 3e-8 away).  Runs the reference's
+ *                           operation order (lazy_normalisation off).  Default 0 = off, as in the reference's production path.
+ *                           May be changed between decompositions.
+ *   "basis_fp32"            1: the resident basis is STORED as fp32 (half the HBM: 4.0 -> 2.0 GB at C3, k = 50), the three
+ *                           vectors the recurrence works on stay fp64, so alpha / beta are those of the fp64 loop bit for
+ *                           bit; lzx_multout_f64 and the host fetch read the rounded columns (6e-8 relative per entry:
+ *                           the centrality vector ends near 1e-8, outside the 1e-10 criterion; the reference's float runs
+ *                           end at 1.2e-6, parallel-final/output/single_double.txt:58-63).  Lazy loop only.  Default 0.
+ *                           SURVEY 8(f) N4.  May be changed between decompositions.
+ * These nine are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
  * "phase_mask", "exchange_at_world_1", ...) exist only in liblzx_dbg.so, the same sources built with -DLZX_DEBUG_KNOBS
  * (`make debug`); tools/perf_probe.py and the tests that need them load that library.                               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "liblzx.so")
 DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
 # what the product library's lzx_set_option knows (include/lzx.h); any other option name selects the debug library
 PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "exchange_fp32",
-                   "lazy_normalisation", "timing_marks_every")
+                   "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -75,6 +75,12 @@ SYMBOLS = [
     ("lzx_lanczos_run", ctypes.c_int, [_h, ctypes.POINTER(LzxStats)]),
     ("lzx_lanczos_fetch_f64", ctypes.c_int, [_h, ctypes.c_uint32, _f64p, _f64p, _f64p]),
     ("lzx_lanczos_fetch_f64_local", ctypes.c_int, [_hp, ctypes.c_int, ctypes.c_uint32, _f64p, _f64p, _f64p]),
+    ("lzx_lanczos_run_steps", ctypes.c_int, [_h, ctypes.c_uint32, ctypes.POINTER(LzxStats)]),
+    ("lzx_lanczos_run_steps_local", ctypes.c_int, [_hp, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(LzxStats)]),
+    ("lzx_lanczos_prepare_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p]),
+    ("lzx_lanczos_progress", ctypes.c_int, [_h, _u32p, _u32p]),
+    ("lzx_multout_change_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
+    ("lzx_multout_change_f64_local", ctypes.c_int, [_hp, ctypes.c_int, _f64p, ctypes.c_uint32, _f64p]),
     ("lzx_device_count", ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     ("lzx_sync", ctypes.c_int, [_h]),
     ("lzx_multout_f64", ctypes.c_int, [_h, _f64p, ctypes.c_uint32, _f64p]),
@@ -231,7 +237,7 @@ class Engine:
         st = LzxStats()
         _check(self.L.lzx_lanczos_f64(self.h, _p(x0, _f64p), k, _p(alpha, _f64p), _p(beta, _f64p),
                                      _p(Q, _f64p) if want_q else None, ctypes.byref(xn), ctypes.byref(st)),
-               "lzx_lanczos_f64")
+               "lzx_lanczos_f64", self.L)
         return alpha, beta[:k - 1], Q, xn.value, st.as_dict()
 
     def lanczos_prepare(self, x0, k: int) -> float:
@@ -245,6 +251,23 @@ class Engine:
         st = LzxStats()
         _check(self.L.lzx_lanczos_run(self.h, ctypes.byref(st)), "lzx_lanczos_run", self.L)
         return st.as_dict()
+
+    def lanczos_run_steps(self, steps: int) -> dict:
+        """Up to `steps` more iterations of the prepared decomposition (lzx_lanczos_run_steps)."""
+        st = LzxStats()
+        _check(self.L.lzx_lanczos_run_steps(self.h, steps, ctypes.byref(st)), "lzx_lanczos_run_steps", self.L)
+        return st.as_dict()
+
+    def lanczos_progress(self):
+        done, prep = ctypes.c_uint32(), ctypes.c_uint32()
+        _check(self.L.lzx_lanczos_progress(self.h, ctypes.byref(done), ctypes.byref(prep)), "lzx_lanczos_progress", self.L)
+        return done.value, prep.value
+
+    def multout_change(self, t) -> float:
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        rc = ctypes.c_double()
+        _check(self.L.lzx_multout_change_f64(self.h, _p(t, _f64p), len(t), ctypes.byref(rc)), "lzx_multout_change_f64", self.L)
+        return rc.value
 
     def lanczos_fetch(self, k: int, want_q: bool = False):
         alpha = np.zeros(k)

@@ -76,6 +76,9 @@ extern "C" void lzx_destroy(lzx_handle c)
     if (c->d_beta) (void)hipFree(c->d_beta);
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->d_iso) (void)hipFree(c->d_iso);
+    if (c->d_Qf) (void)hipFree(c->d_Qf);
+    for (double *&r : c->d_ring) { if (r) (void)hipFree(r); r = nullptr; }
+    for (double *&r : c->d_ymon) { if (r) (void)hipFree(r); r = nullptr; }
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
@@ -95,7 +98,10 @@ extern "C" void lzx_destroy(lzx_handle c)
 extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
 {
     if (!c || !name) LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: bad argument");
-    if (c->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "options must be set before the graph is handed over");
+    // the two options that shape the LOOP, not the graph, may change between decompositions
+    const bool loop_option = !strcmp(name, "reorthogonalise") || !strcmp(name, "basis_fp32");
+    if (c->d_row_ptr && !loop_option) LZX_FAIL(LZX_ERR_STATE, "options must be set before the graph is handed over");
+    if (loop_option && c->k_prep) LZX_FAIL(LZX_ERR_STATE, "a prepared decomposition is in progress");
     if (!strcmp(name, "hub_entries")) c->hub_opt = value;
     else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
     else if (!strcmp(name, "overlap_exchange")) c->overlap_opt = value;
@@ -103,6 +109,8 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "sparse_exchange")) c->sparse_opt = value;
     else if (!strcmp(name, "exchange_fp32")) c->xfp32_opt = value;
     else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
+    else if (!strcmp(name, "reorthogonalise")) c->reorth_opt = value;
+    else if (!strcmp(name, "basis_fp32")) c->qf32_opt = value;
 #ifdef LZX_DEBUG_KNOBS
     // experiment knobs and test hooks: only in liblzx_dbg.so (make debug), which tests/ and tools/perf_probe.py load
     // when they ask for one of these; the product library does not know the names
@@ -192,6 +200,19 @@ static int ensure_capacity(lzx_ctx *c, u32 k)
         LZX_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_beta), sizeof(double) * k));
         c->k_cap = k;
     }
+    if (c->qf32) {
+        // N4: the basis is stored as fp32; the recurrence's three live vectors stay fp64 (d_ring)
+        if (k > c->qf_cols) {
+            if (c->d_Qf) (void)hipFree(c->d_Qf);
+            c->d_Qf = nullptr;
+            c->qf_cols = 0;
+            LZX_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_Qf), sizeof(float) * (size_t)k * c->ldq));
+            c->qf_cols = k;
+        }
+        for (double *&r : c->d_ring)
+            if (!r) LZX_HIP(hipMalloc(reinterpret_cast<void **>(&r), sizeof(double) * c->ldq));
+        return LZX_OK;
+    }
     if (k > c->q_cols) {
         if (c->d_Q) (void)hipFree(c->d_Q);
         c->d_Q = nullptr;
@@ -200,6 +221,18 @@ static int ensure_capacity(lzx_ctx *c, u32 k)
         c->q_cols = k;
     }
     return LZX_OK;
+}
+
+// which form of the loop a decomposition on these handles takes (lanczos_loop)
+static bool loop_is_lazy(const lzx_ctx *c0)
+{
+    if (c0->reorth_opt > 0) return false;   // R1 runs the reference's operation order on the normalised basis
+    return c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (lzx_exchanges(c0) || c0->codes16));
+}
+// fp64 column j of the basis: a column of d_Q, or -- basis stored as fp32 -- one of the three live vectors
+static inline double *basis_col(const lzx_ctx *c, u32 j)
+{
+    return c->qf32 ? c->d_ring[j % 3] : c->d_Q + (size_t)j * c->ldq;
 }
 
 // timing marks on the first handle's stream: the interval that ENDS at a mark is billed to its category
@@ -246,6 +279,14 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     lzx_ctx *c0 = cs[0];
     const u64 n = c0->n;
     const bool multi = lzx_exchanges(c0);
+    const bool lazy = loop_is_lazy(c0);
+    for (lzx_ctx *c : cs) {
+        if (c->reorth_opt != c0->reorth_opt || c->qf32_opt != c0->qf32_opt) LZX_FAIL(LZX_ERR_STATE, "handles carry different loop options");
+        if (c->qf32_opt > 0 && (!lazy || c->basis_u_opt == 0))
+            LZX_FAIL(LZX_ERR_STATE, "basis_fp32 needs the lazy loop (option lazy_normalisation = 1; not together with reorthogonalise)");
+        c->qf32 = c->qf32_opt > 0;
+        c->k_prep = 0;
+    }
 
     // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161).
     double ss = 0.0;
@@ -255,28 +296,34 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
 
     for (lzx_ctx *c : cs) {
         LZX_TRY(ensure_capacity(c, k));
-        c->k_last = 0;
-        // column 0 (its padded rows must be 0) and the zero tail behind every column; columns 1.. are written whole by
-        // the loop (clearing all k columns cost 4 GB of memset at C3)
-        LZX_HIP(hipMemsetAsync(c->d_Q, 0, sizeof(double) * c->ldq, c->stream));
-        if (k > 1)
-            LZX_HIP(hipMemset2DAsync(c->d_Q + c->ldq + c->n_loc_pad, sizeof(double) * c->ldq, 0, sizeof(double) * LZX_TAIL, k - 1, c->stream));
+        c->k_last = c->k_done = 0;
+        c->ymon_valid = 0;
+        double *col0 = basis_col(c, 0);
+        if (c->qf32) {
+            for (double *r : c->d_ring) LZX_HIP(hipMemsetAsync(r, 0, sizeof(double) * c->ldq, c->stream));
+        } else {
+            // column 0 (its padded rows must be 0) and the zero tail behind every column; columns 1.. are written whole by
+            // the loop (clearing all k columns cost 4 GB of memset at C3)
+            LZX_HIP(hipMemsetAsync(c->d_Q, 0, sizeof(double) * c->ldq, c->stream));
+            if (k > 1)
+                LZX_HIP(hipMemset2DAsync(c->d_Q + c->ldq + c->n_loc_pad, sizeof(double) * c->ldq, 0, sizeof(double) * LZX_TAIL, k - 1, c->stream));
+        }
         LZX_HIP(hipMemcpyAsync(c->d_io, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
         // q_0 = x0 / ||x0|| (serial/lib/lanczos.cc:16-17), scattered into the internal order
         if (!multi) {
-            LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_Q, x_norm));
+            LZX_TRY(lzx_launch_permute_in(c, c->d_io, col0, x_norm));
         } else {
             // every rank holds all of x0: full vector in hand-over layout, own slice into the basis, and the
             // prefix of every slice that carries vertices with an edge into the exchange buffer (no communication)
             LZX_TRY(lzx_launch_permute_in(c, c->d_io, c->d_ybuf, x_norm));
-            LZX_HIP(hipMemcpyAsync(c->d_Q, c->d_ybuf + (size_t)c->rank * c->n_loc_pad,
+            LZX_HIP(hipMemcpyAsync(col0, c->d_ybuf + (size_t)c->rank * c->n_loc_pad,
                                    sizeof(double) * c->n_loc_pad, hipMemcpyDeviceToDevice, c->stream));
             LZX_TRY(lzx_launch_relayout(c, c->d_ybuf, c->d_xbuf));
         }
+        if (c->qf32) LZX_TRY(lzx_launch_to_f32(c, col0, c->d_Qf, c->n_loc_pad));   // column 0 of the stored basis
     }
     // the lazy loop (lanczos_loop) carries the rows without an edge as one scalar recurrence
     {
-        const bool lazy = c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (multi || c0->codes16));
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
             c->iso_on = lazy && c->iso_opt != 0;
@@ -284,7 +331,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
             c->basis_u = lazy && c->basis_u_opt != 0;
             // columns 1.. are written by the loop up to rows_live only; with several ranks the exchanged prefix may reach
             // one slice further (into rows without an edge, which nobody reads): keep that slice clean
-            if (c->basis_u && c->iso_on && k > 1 && c->rows_live < c->n_loc_pad)
+            if (!c->qf32 && c->basis_u && c->iso_on && k > 1 && c->rows_live < c->n_loc_pad)
                 LZX_HIP(hipMemset2DAsync(c->d_Q + c->ldq + c->rows_live, sizeof(double) * c->ldq, 0,
                                          sizeof(double) * std::min<u32>(LZX_SLICE, c->n_loc_pad - c->rows_live), k - 1, c->stream));
             if (c->iso_on) LZX_TRY(lzx_launch_iso_prepare(c, k));
@@ -295,15 +342,20 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     return LZX_OK;
 }
 
-// The k-iteration loop proper, on the vectors lanczos_prepare left in HBM.
-static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
+// Iterations [k_done, min(k_prep, k_done + steps)) of the prepared decomposition, on the vectors lanczos_prepare (or the
+// previous call) left in HBM.  Everything an iteration needs from its predecessor lives on the device -- basis columns,
+// alpha / beta, the norm partials, the exchanged vector and its events -- so a decomposition can be advanced in chunks
+// (a convergence monitor that SAVES iterations) with the same bits as in one go.
+static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
 {
     LZX_TRY(check_graphs(cs));
     lzx_ctx *c0 = cs[0];
     const u32 k = c0->k_prep;
     for (lzx_ctx *c : cs)
-        if (c->k_prep == 0 || c->k_prep != k || !c->d_Q || c->q_cols < k)
-            LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_run: no prepared start vector (prepare, then run, with no other call on the handle between them)");
+        if (c->k_prep == 0 || c->k_prep != k || c->k_done != c0->k_done || (c->qf32 ? (!c->d_Qf || c->qf_cols < k) : (!c->d_Q || c->q_cols < k)))
+            LZX_FAIL(LZX_ERR_STATE, "lzx_lanczos_run: no prepared start vector (prepare, then run, with no SpMV / benchmark call on the handle between them)");
+    const u32 j0 = c0->k_done;
+    const u32 j1 = (u32)std::min<u64>(k, (u64)j0 + steps);
     const bool multi = lzx_exchanges(c0);
     LZX_TRY(sync_all(cs));
 
@@ -324,10 +376,10 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     // (w / beta instead of A (u / beta)); one rank keeps the reference's exact operation order below.
     // One rank in blocked mode (whose sums are already ordered differently from the reference's) takes the same form:
     // it saves k_scale's pass over v and a launch; in plain mode one rank keeps the reference's order bit for bit.
-    const bool lazy = c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (multi || c0->codes16));
-    // timing marks on every 4th iteration (every one when k is small); the sums below are scaled to all k
+    const bool lazy = loop_is_lazy(c0);
+    // timing marks on every 4th iteration (every one when k is small); the sums below are scaled to all iterations run
     const u32 every = c0->marks_every_opt > 0 ? (u32)c0->marks_every_opt : (k >= 8 ? 4u : 1u);
-    for (u32 j = 0; lazy && j < k; ++j) {
+    for (u32 j = j0; lazy && j < j1; ++j) {
         const bool first = j == 0, last = j == k - 1;
         LZX_TRY(mk.begin_iteration(j, every));
         if (overlap && j > 0) {
@@ -339,7 +391,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         }
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
-            const double *uj = first ? c->d_Q : (c->basis_u ? c->d_Q + (size_t)j * c->ldq : c->d_u[j & 1]);   // u_0 = q_0
+            const double *uj = first ? basis_col(c, 0) : (c->basis_u ? basis_col(c, j) : c->d_u[j & 1]);   // u_0 = q_0
             SpmvLaunch l{multi ? c->d_xbuf : uj, uj, c->d_v, c->d_partials};
             l.live_rows_only = true;   // k_lazy_update below takes (A u)_i = 0 for rows without an edge
             if (overlap && j > 0) l.chunk1_ready = c->ev_c1;
@@ -359,23 +411,24 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         //  the reduction and its all-reduce are billed to the vector work, the exposed part of the all-gather to comm)
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
-            const double *uj = first ? c->d_Q : (c->basis_u ? c->d_Q + (size_t)j * c->ldq : c->d_u[j & 1]);
+            const double *uj = first ? basis_col(c, 0) : (c->basis_u ? basis_col(c, j) : c->d_u[j & 1]);
             // the resident basis holds u_j (basis_u): nothing normalised is stored, the previous column is divided by
             // beta_{j-2} on the way in, the next one written in place
-            double *q_store = (first || c->basis_u) ? nullptr : c->d_Q + (size_t)j * c->ldq;
-            double *u_store = last ? nullptr : (c->basis_u ? c->d_Q + (size_t)(j + 1) * c->ldq : c->d_u[(j + 1) & 1]);
+            double *q_store = (first || c->basis_u) ? nullptr : basis_col(c, j);
+            double *u_store = last ? nullptr : (c->basis_u ? basis_col(c, j + 1) : c->d_u[(j + 1) & 1]);
+            float *f_store = (c->qf32 && u_store) ? c->d_Qf + (size_t)(j + 1) * c->ldq : nullptr;   // N4: the column as it is stored
             const double *pdiv = (c->basis_u && j >= 2) ? c->d_beta + (j - 2) : nullptr;
             // one rank: both sums are closed in the kernel's prologue from the partials themselves (no reduce launch);
             // the norm partials alternate between two arrays, the kernel reads one while writing the other
             double *p_out = multi ? c->d_partials2 : ((j & 1) ? c->d_partials3 : c->d_partials2);
             const double *p_in = multi ? nullptr : ((j & 1) ? c->d_partials2 : c->d_partials3);
             if (!multi)
-                LZX_TRY(lzx_launch_lazy_update_local(c, c->d_v, c->rows_live, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_partials,
+                LZX_TRY(lzx_launch_lazy_update_local(c, c->d_v, c->rows_live, uj, first ? nullptr : basis_col(c, j - 1), c->d_partials,
                                                      lzx_spmv_partials(c), p_in, first ? 0 : c->np2_last, first ? 1 : 0, c->d_alpha + j,
-                                                     first ? nullptr : c->d_beta + (j - 1), q_store, u_store, p_out, &np2, pdiv));
+                                                     first ? nullptr : c->d_beta + (j - 1), q_store, u_store, p_out, &np2, pdiv, f_store));
             else
-            LZX_TRY(lzx_launch_lazy_update(c, c->d_v, c->rows_live, uj, first ? nullptr : c->d_Q + (size_t)(j - 1) * c->ldq, c->d_scal + 0, first ? 1 : 0,
-                                           c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), q_store, u_store, c->d_partials2, &np2, pdiv));
+            LZX_TRY(lzx_launch_lazy_update(c, c->d_v, c->rows_live, uj, first ? nullptr : basis_col(c, j - 1), c->d_scal + 0, first ? 1 : 0,
+                                           c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), q_store, u_store, c->d_partials2, &np2, pdiv, f_store));
             c->np2_last = np2;
         }
         LZX_TRY(mk.tick(CAT_VEC));
@@ -384,7 +437,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             continue;
         }
         auto next_u = [&](lzx_ctx *c) -> const double * {
-            return c->basis_u ? c->d_Q + (size_t)(j + 1) * c->ldq : c->d_u[(j + 1) & 1];
+            return c->basis_u ? basis_col(c, j + 1) : c->d_u[(j + 1) & 1];
         };
         for (size_t i = 0; i < cs.size(); ++i) {
             src[i] = next_u(cs[i]);
@@ -419,7 +472,8 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             }
         }
     }
-    for (u32 j = 0; !lazy && j < k; ++j) {
+    const u32 reorth = (!lazy && c0->reorth_opt > 0) ? (u32)c0->reorth_opt : 0u;
+    for (u32 j = j0; !lazy && j < j1; ++j) {
         LZX_TRY(mk.begin_iteration(j, every));
         // v = A q_j ; partials of alpha_j
         if (overlap && j > 0) {
@@ -440,7 +494,32 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
         }
         LZX_TRY(mk.tick(CAT_SPMV));
 
-        if (multi) {
+        // R1: the Arnoldi pass of serial/lib/lanczos.cc:85-90 -- A q_j against q_0 .. q_{j-2}, modified Gram-Schmidt in the
+        // reference's order (every inner product over the v the previous update left), as a chain of j launches: the
+        // first forms <v, q_0>, launch t applies vector t - 1 and forms the next inner product, the last one's is
+        // <v, q_j>: the alpha_j partials, which replace those the SpMV formed before the pass.  The partial buffers
+        // alternate so that the last launch writes d_partials3 (k_axpy_norm writes d_partials2 while reading them).
+        const bool re = reorth && j % reorth == 0 && j > 2;
+        u32 np_re = 0;
+        if (re) {
+            for (u32 t = 0; t < j; ++t) {
+                for (lzx_ctx *c : cs) {
+                    LZX_HIP(hipSetDevice(c->device));
+                    double *out = ((j - 1 - t) & 1) ? c->d_partials2 : c->d_partials3;
+                    const double *in = ((j - 1 - t) & 1) ? c->d_partials3 : c->d_partials2;
+                    const double *qm = t == 0 ? nullptr : c->d_Q + (size_t)(t - 1) * c->ldq;
+                    const double *qn = c->d_Q + (size_t)(t + 1 < j ? t : j) * c->ldq;
+                    u32 npo = 0;
+                    LZX_TRY(lzx_launch_mgs_step(c, c->d_v, qm, multi ? nullptr : in, multi ? 0u : np_re, multi ? c->d_scal + 2 : nullptr, qn, out, &npo));
+                    if (multi) LZX_TRY(lzx_launch_reduce(c, out, npo, c->d_scal + (t + 1 < j ? 2 : 0), 0));
+                    if (c == cs.back()) np_re = npo;
+                }
+                if (multi) LZX_TRY(lzx_comm_allreduce_sum(cs, t + 1 < j ? 2 : 0));
+            }
+            LZX_TRY(mk.tick(CAT_VEC));
+        }
+
+        if (multi && !re) {
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
                 LZX_TRY(lzx_launch_reduce(c, c->d_partials, lzx_spmv_partials(c), c->d_scal + 0, 0));
@@ -454,7 +533,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
                 if (multi) LZX_HIP(hipMemcpyAsync(c->d_alpha + j, c->d_scal + 0, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-                else LZX_TRY(lzx_launch_reduce(c, c->d_partials, np, c->d_alpha + j, 0));
+                else LZX_TRY(lzx_launch_reduce(c, re ? c->d_partials3 : c->d_partials, re ? np_re : np, c->d_alpha + j, 0));
             }
             LZX_TRY(mk.tick(CAT_VEC));
             break;
@@ -465,8 +544,8 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             LZX_HIP(hipSetDevice(c->device));
             const double *qj = c->d_Q + (size_t)j * c->ldq;
             const double *qjm1 = j > 0 ? c->d_Q + (size_t)(j - 1) * c->ldq : nullptr;
-            LZX_TRY(lzx_launch_axpy_norm(c, c->d_v, qj, qjm1, multi ? c->d_scal + 0 : c->d_partials,
-                                         multi ? 1 : lzx_spmv_partials(c), c->d_alpha + j,
+            LZX_TRY(lzx_launch_axpy_norm(c, c->d_v, qj, qjm1, multi ? c->d_scal + 0 : (re ? c->d_partials3 : c->d_partials),
+                                         multi ? 1 : (re ? np_re : lzx_spmv_partials(c)), c->d_alpha + j,
                                          j > 0 ? c->d_beta + (j - 1) : nullptr, c->d_partials2, &np2));
         }
         if (multi) LZX_TRY(mk.tick(CAT_VEC));   // one rank: a single mark after k_scale covers both vector kernels
@@ -530,12 +609,16 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
     mk.on = true;
     LZX_TRY(sync_all(cs));
     const auto t1 = std::chrono::steady_clock::now();
-    for (lzx_ctx *c : cs) { c->k_last = k; c->k_prep = 0; }
+    for (lzx_ctx *c : cs) {
+        c->k_done = c->k_last = j1;
+        if (j1 == k) c->k_prep = 0;   // complete: nothing left to resume
+    }
 
     if (stats) {
+        const u32 ran = j1 - j0;
         memset(stats, 0, sizeof *stats);
         stats->loop_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-        stats->iters = k;
+        stats->iters = ran;
         stats->spmv_kernels = c0->pb ? 3 + (c0->pb_finish_grid ? 1 : 0) : 1 + (c0->fin_grid > 0 ? 1 : 0);
         stats->spmv_bytes = spmv_algorithmic_bytes(c0);
         stats->spmv_ms_min = 1e300;
@@ -550,8 +633,8 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, lzx_stats *stats)
             }
         }
         if (stats->spmv_ms_min == 1e300) stats->spmv_ms_min = 0.0;
-        if (mk.sampled > 0 && mk.sampled < k) {   // marks were carried by `sampled` of the k iterations: scale the sums
-            const double f = (double)k / (double)mk.sampled;
+        if (mk.sampled > 0 && mk.sampled < ran) {   // marks were carried by `sampled` of the iterations: scale the sums
+            const double f = (double)ran / (double)mk.sampled;
             stats->spmv_ms *= f;
             stats->vec_ms *= f;
             stats->comm_ms *= f;
@@ -587,14 +670,20 @@ static int lanczos_fetch(std::vector<lzx_ctx *> &cs, u32 k, double *alpha, doubl
         for (u32 j = 0; j < k; ++j) {
             if (multi) {
                 for (size_t i = 0; i < cs.size(); ++i) {
-                    src[i] = cs[i]->d_Q + (size_t)j * cs[i]->ldq;
-                    dst[i] = cs[i]->d_ybuf;
+                    lzx_ctx *c = cs[i];
+                    if (c->qf32) {   // the stored column, widened (this rank's slice goes through d_v)
+                        LZX_HIP(hipSetDevice(c->device));
+                        LZX_TRY(lzx_launch_widen_col(c, j, c->d_v));
+                    }
+                    src[i] = c->qf32 ? c->d_v : c->d_Q + (size_t)j * c->ldq;
+                    dst[i] = c->d_ybuf;
                 }
                 LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->n_loc_pad));
             }
             LZX_HIP(hipSetDevice(c0->device));
+            if (!multi && c0->qf32) LZX_TRY(lzx_launch_widen_col(c0, j, c0->d_ybuf));
             // columns of the lazy loop hold u_j = beta_{j-1} q_j: the division the loop itself applies, on the way out
-            LZX_TRY(lzx_launch_permute_out(c0, multi ? c0->d_ybuf : c0->d_Q + (size_t)j * c0->ldq, c0->d_io,
+            LZX_TRY(lzx_launch_permute_out(c0, (multi || c0->qf32) ? c0->d_ybuf : c0->d_Q + (size_t)j * c0->ldq, c0->d_io,
                                            (c0->basis_u && j > 0) ? c0->d_beta + (j - 1) : nullptr));
             LZX_HIP(hipMemcpyAsync(Q + (size_t)j * n, c0->d_io, sizeof(double) * n, hipMemcpyDeviceToHost, c0->stream));
             LZX_TRY(sync_all(cs));
@@ -608,7 +697,7 @@ static int lanczos_run(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, doub
 {
     if (!x0 || !alpha || k == 0 || (k > 1 && !beta)) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_f64: bad argument");
     LZX_TRY(lanczos_prepare(cs, x0, k, x_norm_out));
-    LZX_TRY(lanczos_loop(cs, stats));
+    LZX_TRY(lanczos_loop(cs, k, stats));
     return lanczos_fetch(cs, k, alpha, beta, Q);
 }
 
@@ -631,7 +720,38 @@ extern "C" int lzx_lanczos_run(lzx_handle h, lzx_stats *stats)
 {
     std::vector<lzx_ctx *> cs;
     LZX_TRY(gather_handles(h, cs));
-    return lanczos_loop(cs, stats);
+    return lanczos_loop(cs, 0xffffffffu, stats);
+}
+
+extern "C" int lzx_lanczos_run_steps(lzx_handle h, uint32_t steps, lzx_stats *stats)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    if (steps == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_run_steps: steps == 0");
+    return lanczos_loop(cs, steps, stats);
+}
+
+extern "C" int lzx_lanczos_run_steps_local(lzx_handle *hs, int world, uint32_t steps, lzx_stats *stats)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles_local(hs, world, cs));
+    if (steps == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_run_steps: steps == 0");
+    return lanczos_loop(cs, steps, stats);
+}
+
+extern "C" int lzx_lanczos_prepare_f64_local(lzx_handle *hs, int world, const double *x0, uint32_t k, double *x_norm)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles_local(hs, world, cs));
+    return lanczos_prepare(cs, x0, k, x_norm);
+}
+
+extern "C" int lzx_lanczos_progress(lzx_handle h, uint32_t *done, uint32_t *prepared)
+{
+    if (!h) LZX_FAIL(LZX_ERR_ARG, "lzx_lanczos_progress: null handle");
+    if (done) *done = h->k_done;
+    if (prepared) *prepared = h->k_prep;
+    return LZX_OK;
 }
 
 extern "C" int lzx_lanczos_fetch_f64(lzx_handle h, uint32_t k, double *alpha, double *beta, double *Q)
@@ -726,13 +846,15 @@ static int multout_run(std::vector<lzx_ctx *> &cs, const double *t, u32 k, doubl
     const bool multi = lzx_exchanges(c0);
     for (lzx_ctx *c : cs)
         if (c->k_last < k) LZX_FAIL(LZX_ERR_STATE, "lzx_multout_f64: the resident basis has %u vectors, %u asked", c->k_last, k);
-    for (lzx_ctx *c : cs) c->k_prep = 0;   // uses the work vectors (see spmv_run)
+    // (touches d_v, d_partials and d_ybuf only: all dead between two iterations of the loop, so a decomposition that is
+    //  being advanced in chunks -- lzx_lanczos_run_steps -- stays resumable across this call)
     std::vector<const double *> src(cs.size());
     std::vector<double *> dst(cs.size());
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
-        // the k coefficients are staged in the (idle) block-partials buffer
-        if (2 * (u64)k > c->np_cap) LZX_FAIL(LZX_ERR_LIMIT, "k = %u exceeds the staging capacity %u", k, c->np_cap / 2);
+        // the k coefficients are staged in the (idle) block-partials buffer; the unnormalised basis needs k more behind them
+        if ((u64)k * (c->basis_u ? 2u : 1u) > c->np_cap)
+            LZX_FAIL(LZX_ERR_LIMIT, "k = %u exceeds the staging capacity %u", k, c->np_cap / (c->basis_u ? 2u : 1u));
         LZX_HIP(hipMemcpyAsync(c->d_partials, t, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
         LZX_TRY(lzx_launch_multout(c, c->d_partials, k, c->d_v));
     }
@@ -758,6 +880,51 @@ extern "C" int lzx_multout_f64_local(lzx_handle *hs, int world, const double *t,
     std::vector<lzx_ctx *> cs;
     LZX_TRY(gather_handles_local(hs, world, cs));
     return multout_run(cs, t, k, ans);
+}
+
+// Convergence monitor on the device: y = Q_k t is formed as in lzx_multout_f64 but stays in HBM; what comes back is
+// ||y - y_prev|| / ||y|| against the answer of the previous call since the last prepare (1.0 for the first one).
+static int multout_change_run(std::vector<lzx_ctx *> &cs, const double *t, u32 k, double *rel_change)
+{
+    if (!t || !rel_change || k == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_multout_change_f64: bad argument");
+    LZX_TRY(check_graphs(cs));
+    lzx_ctx *c0 = cs[0];
+    for (lzx_ctx *c : cs)
+        if (c->k_last < k) LZX_FAIL(LZX_ERR_STATE, "lzx_multout_change_f64: the resident basis has %u vectors, %u asked", c->k_last, k);
+    const bool have_prev = c0->ymon_valid > 0;
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        for (double *&y : c->d_ymon)
+            if (!y) LZX_HIP(hipMalloc(reinterpret_cast<void **>(&y), sizeof(double) * c->n_loc_pad));
+        if ((u64)k * (c->basis_u ? 2u : 1u) > c->np_cap)
+            LZX_FAIL(LZX_ERR_LIMIT, "k = %u exceeds the staging capacity %u", k, c->np_cap / (c->basis_u ? 2u : 1u));
+        double *cur = c->d_ymon[c->ymon_valid & 1], *prev = c->d_ymon[(c->ymon_valid + 1) & 1];
+        LZX_HIP(hipMemcpyAsync(c->d_partials, t, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+        LZX_TRY(lzx_launch_multout(c, c->d_partials, k, cur));
+        LZX_TRY(lzx_launch_change(c, cur, have_prev ? prev : cur, c->d_scal + 5));
+        ++c->ymon_valid;
+    }
+    if (lzx_exchanges(c0)) LZX_TRY(lzx_comm_allreduce_sum(cs, 5, 2));
+    double two[2] = {0.0, 0.0};
+    LZX_HIP(hipSetDevice(c0->device));
+    LZX_HIP(hipMemcpyAsync(two, c0->d_scal + 5, sizeof two, hipMemcpyDeviceToHost, c0->stream));
+    LZX_TRY(sync_all(cs));
+    *rel_change = have_prev ? std::sqrt(two[0]) / std::sqrt(two[1]) : 1.0;
+    return LZX_OK;
+}
+
+extern "C" int lzx_multout_change_f64(lzx_handle h, const double *t, uint32_t k, double *rel_change)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles(h, cs));
+    return multout_change_run(cs, t, k, rel_change);
+}
+
+extern "C" int lzx_multout_change_f64_local(lzx_handle *hs, int world, const double *t, uint32_t k, double *rel_change)
+{
+    std::vector<lzx_ctx *> cs;
+    LZX_TRY(gather_handles_local(hs, world, cs));
+    return multout_change_run(cs, t, k, rel_change);
 }
 
 // --------------------------------------------------------------------------------------------------

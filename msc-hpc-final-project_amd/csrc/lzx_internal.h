@@ -240,7 +240,22 @@ struct lzx_ctx {
     double *d_Q = nullptr;             // [q_cols][ldq]
     u32 q_cols = 0;
     u32 k_last = 0;                    // valid basis vectors from the last decomposition
-    u32 k_prep = 0;                    // iterations a prepared (not yet run) decomposition will take
+    u32 k_prep = 0;                    // iterations a prepared decomposition will take in all (0: nothing prepared)
+    u32 k_done = 0;                    // ... of which this many have run (lzx_lanczos_run_steps continues from here)
+    // R1 (serial/lib/lanczos.cc:58-132, decompose_with_arnoldi): every reorth_opt iterations (j % e == 0 && j > 2) A q_j is
+    // orthogonalised against q_0 .. q_{j-2} (modified Gram-Schmidt, the reference's order) before alpha_j is taken; the
+    // reference hard-codes e = 2.  0 / -1: off.  Runs the reference-order loop (normalised basis, every row elementwise).
+    int64_t reorth_opt = -1;
+    // N4 remainder: the resident basis is STORED as fp32 (d_Qf), the recurrence keeps its three live vectors in fp64
+    // (d_ring); lzx_multout and the host fetch read the fp32 columns.  Lazy loop only.  Off by default.
+    int64_t qf32_opt = -1;
+    bool qf32 = false;                 // the last prepared decomposition stores its basis that way
+    float *d_Qf = nullptr;             // [qf_cols][ldq]
+    u32 qf_cols = 0;
+    double *d_ring[3] = {nullptr, nullptr, nullptr};   // [ldq] each: u_{j-1}, u_j, u_{j+1} (column j lives in d_ring[j % 3])
+    // convergence monitor on the device (lzx_multout_change_f64): the last two evaluated answers, this rank's slice
+    double *d_ymon[2] = {nullptr, nullptr};            // [n_loc_pad] each
+    u32 ymon_valid = 0;                // answers evaluated since the last prepare (0: no previous one to compare with)
     double *d_xbuf = nullptr;          // [xlen] exchange buffer the SpMV gathers from (world > 1, hooks)
     double *d_ybuf = nullptr;          // [iolen] full-length buffer in hand-over layout (hooks, multout, fetch)
     double *d_io = nullptr;            // [n] staging in the caller's order
@@ -292,10 +307,11 @@ int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u
 int lzx_launch_iso_prepare(lzx_ctx *c, u32 k);                       // sum of squares of q_0 over the rows without an edge, c_0 = d_0 = 1
 int lzx_launch_iso_fill(lzx_ctx *c, u32 k);                          // q_j[i] = c_j q_0[i] for those rows, j = 1 .. k - 1
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
-                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr);
+                           double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr,
+                           float *f32_next = nullptr);
 int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,
                                  const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
-                                 double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr);
+                                 double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr, float *f32_next = nullptr);
 // v -= alpha q_j (+ beta_prev q_jm1); alpha = sum(partials_in); writes alpha_out; partial ||v||^2 out.
 int lzx_launch_axpy_norm(lzx_ctx *c, double *v, const double *qj, const double *qjm1,
                          const double *partials_in, u32 np_in, double *alpha_out,
@@ -308,6 +324,14 @@ int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io_old_order,
 // hand-over layout (stride n_loc_pad) -> exchange layout (stride xs): the active prefix of every rank's slice
 int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_layout);
 int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc);
+// one step of the Arnoldi pass (serial/lib/lanczos.cc:86-90): v -= d q_m (d = sum of d_partials[0..d_np), or *d_scal when
+// d_np == 0; q_m == nullptr: no update), then per-block partials of v . q_next
+int lzx_launch_mgs_step(lzx_ctx *c, double *v, const double *q_m, const double *d_partials, u32 d_np, const double *d_scal,
+                        const double *q_next, double *partials_out, u32 *np_out);
+// partial sums of |y - y_prev|^2 and |y|^2 over this rank's rows -> out2[0..1] (device)
+int lzx_launch_change(lzx_ctx *c, const double *y, const double *y_prev, double *out2);
+// column `col` of the fp32 basis, widened to fp64 into out[0..n_loc_pad)
+int lzx_launch_widen_col(lzx_ctx *c, u32 col, double *out);
 
 // ---- lzx_comm.hip ----
 // does the Lanczos loop exchange vectors / reduce scalars through the communicator?

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict__ u, const double *__restrict__ q_prev,
               const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
               double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n, double *iso, u32 iso_k, u32 iso_j,
-              const double *prev_div)
+              const double *prev_div, float *f32_next)
 {
     __shared__ double sh[4];
     double D, B;
@@ -194,6 +194,7 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
                 t.y -= beta * p.y;
             }
             *reinterpret_cast<double2 *>(u_next + i) = t;
+            if (f32_next) *reinterpret_cast<float2 *>(f32_next + i) = make_float2((float)t.x, (float)t.y);   // basis stored as fp32 (N4)
             nrm += t.x * t.x;
             nrm += t.y * t.y;
         }
@@ -296,8 +297,9 @@ __global__ void k_permute_out(const double *full, const u32 *gidx, double *io, u
 // device-resident basis; one thread per row, basis vectors streamed with unit stride.
 // iso != nullptr: rows [rows_act, n) are kept as q_j[i] = iso[j] q_0[i] (lzx_internal.h: iso_on).
 // tq: the coefficients the stored columns are multiplied by (t itself, or t_j / beta_{j-1} when the columns hold u_j).
+template <typename QT>
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
-k_multout(const double *Q, u32 ldq, const double *t, const double *tq, u32 k, double *out, u32 n, u32 rows_act, const double *iso)
+k_multout(const QT *Q, u32 ldq, const double *t, const double *tq, u32 k, double *out, u32 n, u32 rows_act, const double *iso)
 {
     const u32 i = blockIdx.x * LZX_VEC_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -343,12 +345,73 @@ k_iso_prepare(const double *partials, u32 np, double *iso, u32 iso_k)
 }
 
 // basis columns 1 .. k-1 of the rows without an edge, materialised: q_j[i] = c_j q_0[i]
-__global__ void k_iso_fill(double *Q, u32 ldq, u32 k, u32 r0, u32 r1, const double *coeff)
+template <typename QT>
+__global__ void k_iso_fill(QT *Q, u32 ldq, u32 k, u32 r0, u32 r1, const double *coeff)
 {
     const u32 i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r1) return;
     const double z = Q[i];
-    for (u32 j = 1; j < k; ++j) Q[(size_t)j * ldq + i] = coeff[j] * z;
+    for (u32 j = 1; j < k; ++j) Q[(size_t)j * ldq + i] = (QT)(coeff[j] * z);
+}
+
+// One step of the Arnoldi pass of serial/lib/lanczos.cc:85-90 (decompose_with_arnoldi), fused the way the dependent
+// chain allows: this launch applies the update of basis vector m (v -= dot_m q_m, dot_m closed here from the previous
+// launch's partials, in every workgroup the same fixed order) and forms the partials of the NEXT inner product
+// <v, q_next> over the updated v -- q_{m+1} inside the pass, q_j (the alpha_j partials) behind its last vector.
+// q_m == nullptr: the pass's first launch, inner product only.  Modified Gram-Schmidt, the reference's order: every
+// inner product sees the v the previous update left.
+__global__ void __launch_bounds__(LZX_VEC_BLOCK)
+k_mgs_step(double *v, const double *__restrict__ q_m, const double *d_partials, u32 d_np, const double *d_scal,
+           const double *__restrict__ q_next, double *partials_out, u32 n)
+{
+    __shared__ double sh[4];
+    double d = 0.0;
+    if (q_m) d = d_np ? block_sum_fixed_256(d_partials, d_np, sh) : *d_scal;
+    double acc = 0.0;
+    const u32 stride = gridDim.x * LZX_VEC_BLOCK * 2;
+    for (u32 i = (blockIdx.x * LZX_VEC_BLOCK + threadIdx.x) * 2; i < n; i += stride) {
+        double2 w = *reinterpret_cast<const double2 *>(v + i);
+        if (q_m) {
+            const double2 q = *reinterpret_cast<const double2 *>(q_m + i);
+            w.x -= d * q.x;
+            w.y -= d * q.y;
+            *reinterpret_cast<double2 *>(v + i) = w;
+        }
+        const double2 p = *reinterpret_cast<const double2 *>(q_next + i);
+        acc += w.x * p.x;
+        acc += w.y * p.y;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials_out[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// convergence monitor: per-block partials of |y - y_prev|^2 (first half of `partials`) and |y|^2 (second half)
+__global__ void __launch_bounds__(LZX_VEC_BLOCK)
+k_change_partials(const double *__restrict__ y, const double *__restrict__ yp, double *partials, u32 n)
+{
+    __shared__ double sh[8];
+    double d2 = 0.0, y2 = 0.0;
+    for (u32 i = blockIdx.x * LZX_VEC_BLOCK + threadIdx.x; i < n; i += gridDim.x * LZX_VEC_BLOCK) {
+        const double a = y[i], df = a - yp[i];
+        d2 += df * df;
+        y2 += a * a;
+    }
+    d2 = wave_sum(d2);
+    y2 = wave_sum(y2);
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = d2; sh[4 + (threadIdx.x >> 6)] = y2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        partials[gridDim.x + blockIdx.x] = ((sh[4] + sh[5]) + sh[6]) + sh[7];
+    }
+}
+
+__global__ void k_widen_col(const float *in, double *out, u32 n)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -498,12 +561,12 @@ int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u
 
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out,
-                           const double *prev_div)
+                           const double *prev_div, float *f32_next)
 {
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
                        first, alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div);
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next);
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
@@ -511,14 +574,43 @@ int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double
 
 int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,
                                  const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
-                                 double *u_next, double *partials_out, u32 *np_out, const double *prev_div)
+                                 double *u_next, double *partials_out, u32 *np_out, const double *prev_div, float *f32_next)
 {
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, nullptr, pa, na, pb, nb, first,
                        alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div);
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next);
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
+    return LZX_OK;
+}
+
+int lzx_launch_mgs_step(lzx_ctx *c, double *v, const double *q_m, const double *d_partials, u32 d_np, const double *d_scal,
+                        const double *q_next, double *partials_out, u32 *np_out)
+{
+    const u32 g = vec_grid(c);
+    hipLaunchKernelGGL(k_mgs_step, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, v, q_m, d_partials, d_np, d_scal, q_next,
+                       partials_out, c->n_loc_pad);
+    LZX_HIP(hipGetLastError());
+    *np_out = g;
+    return LZX_OK;
+}
+
+int lzx_launch_change(lzx_ctx *c, const double *y, const double *y_prev, double *out2)
+{
+    // two fixed-shape steps: per-block partials (both sums side by side in d_partials, which is dead between two
+    // iterations of the loop -- d_partials2 / 3 are not: they carry the norm partials), then one block closes them
+    const u32 g = std::min<u32>(vec_grid(c), c->np_cap / 2);
+    hipLaunchKernelGGL(k_change_partials, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, y, y_prev, c->d_partials, c->n_loc_pad);
+    hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_partials, g, c->d_partials + g, g, out2);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_widen_col(lzx_ctx *c, u32 col, double *out)
+{
+    hipLaunchKernelGGL(k_widen_col, dim3((c->n_loc_pad + 255) / 256), dim3(256), 0, c->stream, c->d_Qf + (size_t)col * c->ldq, out, c->n_loc_pad);
+    LZX_HIP(hipGetLastError());
     return LZX_OK;
 }
 
@@ -604,11 +696,17 @@ int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc)
     const u32 g = (c->n_loc_pad + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
     const bool factored = c->iso_on && !c->iso_filled;
     const double *tq = t_dev;
+    if ((u64)k * (c->basis_u ? 2u : 1u) > c->np_cap)   // t (and, with the unnormalised basis, k more doubles) live in a partials buffer
+        LZX_FAIL(LZX_ERR_LIMIT, "lzx_launch_multout: k = %u does not fit the coefficient staging (%u doubles)", k, c->np_cap);
     if (c->basis_u) {   // the caller left room for k more doubles behind t
         hipLaunchKernelGGL(k_multout_coeff, dim3((k + 255) / 256), dim3(256), 0, c->stream, t_dev, c->d_beta, k, const_cast<double *>(t_dev) + k);
         tq = t_dev + k;
     }
-    hipLaunchKernelGGL(k_multout, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Q, c->ldq, t_dev, tq, k,
+    if (c->qf32)
+        hipLaunchKernelGGL(k_multout<float>, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Qf, c->ldq, t_dev, tq, k,
+                           out_loc, c->n_loc_pad, c->rows_live, factored ? c->d_iso : nullptr);
+    else
+    hipLaunchKernelGGL(k_multout<double>, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Q, c->ldq, t_dev, tq, k,
                        out_loc, c->n_loc_pad, c->rows_live, factored ? c->d_iso : nullptr);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
@@ -625,7 +723,7 @@ int lzx_launch_iso_prepare(lzx_ctx *c, u32 k)
     }
     LZX_HIP(hipMemsetAsync(c->d_iso, 0, sizeof(double) * (2 * (size_t)c->iso_cap + 4), c->stream));
     const u32 g = std::min<u32>(256u, c->np_cap);
-    hipLaunchKernelGGL(k_iso_sumsq, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_Q, c->rows_live, c->n_loc_pad, c->d_partials3);
+    hipLaunchKernelGGL(k_iso_sumsq, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, c->qf32 ? c->d_ring[0] : c->d_Q, c->rows_live, c->n_loc_pad, c->d_partials3);
     hipLaunchKernelGGL(k_iso_prepare, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, c->d_partials3, g, c->d_iso, c->iso_cap);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
@@ -635,8 +733,11 @@ int lzx_launch_iso_fill(lzx_ctx *c, u32 k)
 {
     if (k > 1 && c->n_loc_pad > c->rows_live) {
         const u32 rows = c->n_loc_pad - c->rows_live;
-        hipLaunchKernelGGL(k_iso_fill, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Q, c->ldq, k, c->rows_live, c->n_loc_pad,
-                           c->basis_u ? c->d_iso + c->iso_cap + 1 : c->d_iso);   // d_j where the columns hold u_j, c_j otherwise
+        const double *coeff = c->basis_u ? c->d_iso + c->iso_cap + 1 : c->d_iso;   // d_j where the columns hold u_j, c_j otherwise
+        if (c->qf32)
+            hipLaunchKernelGGL(k_iso_fill<float>, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Qf, c->ldq, k, c->rows_live, c->n_loc_pad, coeff);
+        else
+        hipLaunchKernelGGL(k_iso_fill<double>, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Q, c->ldq, k, c->rows_live, c->n_loc_pad, coeff);
         LZX_HIP(hipGetLastError());
     }
     return LZX_OK;

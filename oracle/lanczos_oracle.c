@@ -122,6 +122,55 @@ int orc_lanczos(uint64_t n, const uint64_t *row_offset, const uint32_t *col_idx,
     return 0;
 }
 
+/* lanczosDecomp::decompose_with_arnoldi: serial/lib/lanczos.cc:58-132 -- decompose() with an Arnoldi
+ * (modified Gram-Schmidt) pass every `every` iterations (the reference hard-codes reorthog_every_k = 2, :71):
+ *   for j in 0..k-1:
+ *     v = A Q_s[i]                                                          (82)
+ *     if j % every == 0 and j > 2:                                          (85)
+ *       for m in 0..j-2:  dot = <v, q_m>;  v -= dot * q_m   (sequential, each dot over the UPDATED v)  (86-90)
+ *     alpha[j] = <v, Q_s[i]>; v -= alpha[j] Q_s[i]; v -= beta[j-1] Q_s[1-i]  (94-105)
+ *     beta[j] = ||v||; Q_s[1-i] = v / beta[j]                    (j < k-1)  (107-112)
+ *     q_j kept as a contiguous vector for the later passes                  (115-118)
+ * Q (k contiguous vectors, the Q_col_maj layout of :65-67) must not be NULL: the pass reads it.  Returns 0 / -1. */
+int orc_lanczos_arnoldi(uint64_t n, const uint64_t *row_offset, const uint32_t *col_idx,
+                        uint32_t k, uint32_t every, const double *x, double *alpha, double *beta,
+                        double *Q, double *x_norm_out)
+{
+    if (!Q || every == 0) return -1;
+    double *v = (double *)malloc(sizeof(double) * n);
+    double *Q_raw = (double *)malloc(sizeof(double) * 2 * n);
+    if (!v || !Q_raw) { free(v); free(Q_raw); return -1; }
+    double *Q_s[2] = { Q_raw, Q_raw + n };
+    unsigned i = 0;
+    const double x_norm = orc_norm(n, x);
+    if (x_norm_out) *x_norm_out = x_norm;
+    for (uint64_t r = 0; r < n; ++r) Q_s[i][r] = x[r] / x_norm;
+
+    for (uint32_t j = 0; j < k; ++j) {
+        orc_spmv(n, row_offset, col_idx, Q_s[i], v);
+        if (j % every == 0 && j > 2) {
+            for (uint32_t m = 0; m + 1 < j; ++m) {
+                const double *qm = Q + (uint64_t)m * n;
+                const double dot = orc_inner_prod(n, v, qm);
+                for (uint64_t r = 0; r < n; ++r) v[r] -= dot * qm[r];
+            }
+        }
+        alpha[j] = orc_inner_prod(n, v, Q_s[i]);
+        for (uint64_t r = 0; r < n; ++r) v[r] -= alpha[j] * Q_s[i][r];
+        if (j > 0)
+            for (uint64_t r = 0; r < n; ++r) v[r] -= beta[j - 1] * Q_s[1 - i][r];
+        if (j < k - 1) {
+            beta[j] = orc_norm(n, v);
+            for (uint64_t r = 0; r < n; ++r) Q_s[1 - i][r] = v[r] / beta[j];
+        }
+        memcpy(Q + (uint64_t)j * n, Q_s[i], sizeof(double) * n);
+        i = 1 - i;
+    }
+    free(v);
+    free(Q_raw);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* CSR from a sorted, de-duplicated list of directed-edge keys
  * key = (row << 32) | col.  Restates the emission loop of

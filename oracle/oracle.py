@@ -62,6 +62,9 @@ def lib() -> ctypes.CDLL:
                                   _f64p, _f64p, _f64p, ctypes.c_int, _f64p,
                                   ctypes.c_void_p, ctypes.c_void_p]
         L.orc_lanczos.restype = ctypes.c_int
+        L.orc_lanczos_arnoldi.argtypes = [ctypes.c_uint64, _u64p, _u32p, ctypes.c_uint32, ctypes.c_uint32, _f64p,
+                                          _f64p, _f64p, _f64p, _f64p]
+        L.orc_lanczos_arnoldi.restype = ctypes.c_int
         L.orc_csr_from_keys.argtypes = [ctypes.c_uint64, ctypes.c_uint64, _u64p, _u64p, _u32p]
         L.orc_csr_from_keys.restype = None
         L.orc_gen_er_keys.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _u64p]
@@ -159,6 +162,22 @@ def lanczos(row_offset, col_idx, k: int, x, want_q: bool = True, q_colmajor: boo
     return alpha, beta[:k - 1], Q, xn.value
 
 
+def lanczos_arnoldi(row_offset, col_idx, k: int, x, every: int = 2):
+    """serial/lib/lanczos.cc:58-132 (decompose_with_arnoldi; the reference's every = 2).  Returns (alpha[k],
+    beta[k-1], Q (k, n), x_norm)."""
+    n = len(row_offset) - 1
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    alpha = np.zeros(k)
+    beta = np.zeros(max(k - 1, 1))
+    Q = np.zeros((k, n))
+    xn = ctypes.c_double(0.0)
+    rc = lib().orc_lanczos_arnoldi(n, _p(row_offset, _u64p), _p(col_idx, _u32p), k, every, _p(x, _f64p),
+                                   _p(alpha, _f64p), _p(beta, _f64p), _p(Q, _f64p), ctypes.byref(xn))
+    if rc != 0:
+        raise MemoryError("orc_lanczos_arnoldi")
+    return alpha, beta[:k - 1], Q, xn.value
+
+
 def eigen(alpha, beta):
     """T = V diag(lam) V^T. V[i, j] = i-th component of eigenvector j (LAPACK_ROW_MAJOR 'V')."""
     from scipy.linalg import eigh_tridiagonal
@@ -237,3 +256,53 @@ class RefGraph:
         if self.h:
             self.R.ref_free(self.h)
             self.h = None
+
+
+# --------------------------------------------------------------------------- accuracy referee
+_REFEREE = None
+
+
+def referee_lib():
+    """oracle/libreferee.so (referee.c): the same recurrence in x87 extended precision, optional full
+    re-orthogonalisation.  Test infrastructure: more accurate than the oracle AND the engine, so k = 50 tolerances can
+    be anchored to it."""
+    global _REFEREE
+    if _REFEREE is None:
+        so = os.path.join(_HERE, "libreferee.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "referee"])
+        R = ctypes.CDLL(so)
+        R.ref_expm_ld.argtypes = [ctypes.c_uint64, _u64p, _u32p, ctypes.c_uint32, _f64p, ctypes.c_int, ctypes.c_uint32,
+                                  _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
+        R.ref_expm_ld.restype = ctypes.c_int
+        R.ref_spmv_ld.argtypes = [ctypes.c_uint64, _u64p, _u32p, _f64p, _f64p]
+        R.ref_spmv_ld.restype = ctypes.c_int
+        _REFEREE = R
+    return _REFEREE
+
+
+def referee_expm(row_offset, col_idx, k: int, x, caps=(0.0, 40.0), reorth: int = 0):
+    """Extended-precision k-step Lanczos e^(s (A - theta_max)) x.  caps: one answer per entry -- cap > 0: s = min(1, cap /
+    theta_max) (tests' shift_weights(cap)); 0: s = 1 (shift_weights(cap=None)); < 0: the unshifted e^A x.
+    reorth: 0 none, 1 full (two MGS sweeps every iteration), 2 the reference's decompose_with_arnoldi schedule.
+    Returns dict(ans=(len(caps), n) float64, alpha, beta, lam, orth_loss)."""
+    n = len(row_offset) - 1
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    caps = np.ascontiguousarray(caps, dtype=np.float64)
+    ans = np.empty((len(caps), n))
+    alpha, beta, lam = np.zeros(k), np.zeros(max(k - 1, 1)), np.zeros(k)
+    loss = ctypes.c_double(0.0)
+    rc = referee_lib().ref_expm_ld(n, _p(row_offset, _u64p), _p(col_idx, _u32p), k, _p(x, _f64p), reorth, len(caps),
+                                   _p(caps, _f64p), _p(ans, _f64p), _p(alpha, _f64p), _p(beta, _f64p), _p(lam, _f64p),
+                                   ctypes.byref(loss))
+    if rc != 0:
+        raise MemoryError("ref_expm_ld")
+    return dict(ans=ans, alpha=alpha, beta=beta[:k - 1], lam=lam, orth_loss=loss.value)
+
+
+def referee_spmv(row_offset, col_idx, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty(len(row_offset) - 1)
+    if referee_lib().ref_spmv_ld(len(y), _p(row_offset, _u64p), _p(col_idx, _u32p), _p(x, _f64p), _p(y, _f64p)) != 0:
+        raise MemoryError("ref_spmv_ld")
+    return y

@@ -102,3 +102,54 @@ def test_generators_edge_cases(oracle):
     for r in range(700):                              # ascending columns within a row
         seg = ci[int(ro[r]):int(ro[r + 1])]
         assert np.all(np.diff(seg.astype(np.int64)) > 0)
+
+
+def test_referee_agrees_with_oracle_and_with_itself(oracle):
+    """oracle/referee.c (x87 extended precision, test infrastructure): on small well-conditioned fixtures it must agree
+    with the fp64 oracle to fp64 rounding, with and without full re-orthogonalisation, in all three functionals; its
+    SpMV is the oracle's up to the last bit of a short positive sum."""
+    O = oracle
+    for rp, ci, k in ((*O.gen_er(4000, 40000, 5), 20), (*O.gen_rmat(12, 3000, 30000, 9), 16)):
+        n = len(rp) - 1
+        x0 = 0.5 + np.random.default_rng(1).random(n)
+        a, b, Q, xn = O.lanczos(rp, ci, k, x0, q_colmajor=True)
+        lam, V = O.eigen(a, b)
+        plain = (V @ (np.exp(lam) * (xn * V[0, :]))) @ Q
+        shifted = (V @ (np.exp(lam - lam.max()) * (xn * V[0, :]))) @ Q
+        s = min(1.0, 40.0 / lam.max())
+        capped = (V @ (np.exp(s * (lam - lam.max())) * (xn * V[0, :]))) @ Q
+        for reorth in (0, 1):
+            R = O.referee_expm(rp, ci, k, x0, caps=(-1.0, 0.0, 40.0), reorth=reorth)
+            for got, want in zip(R["ans"], (plain, shifted, capped)):
+                assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max(), reorth
+            assert abs(R["alpha"][0] - a[0]) <= 1e-14 * abs(a[0]) and abs(R["beta"][0] - b[0]) <= 1e-13 * abs(b[0])
+            assert abs(R["lam"].max() - lam.max()) <= 1e-10 * lam.max()
+        assert R["orth_loss"] <= 1e-15
+        y = O.referee_spmv(rp, ci, x0)
+        assert np.allclose(y, O.spmv(rp, ci, x0), rtol=1e-14, atol=0)
+
+
+def test_arnoldi_restatement(oracle):
+    """orc_lanczos_arnoldi restates serial/lib/lanczos.cc:58-132.  While the basis is still orthogonal the pass removes
+    nothing but rounding, so it must reproduce the plain loop's answer; with every = 1 it keeps the basis orthogonal where
+    the plain loop loses it (hub-heavy R-MAT), and the result then agrees with the fully re-orthogonalised referee."""
+    O = oracle
+    rp, ci = O.gen_er(4000, 40000, 5)
+    x0 = np.ones(4000)
+    a, b, Q, xn = O.lanczos(rp, ci, 12, x0, q_colmajor=True)
+    for every in (1, 2, 3):
+        a2, b2, Q2, xn2 = O.lanczos_arnoldi(rp, ci, 12, x0, every=every)
+        assert xn2 == xn and np.array_equal(a2[:3], a[:3]) and np.array_equal(Q2[:4], Q[:4])   # untouched before j = 3 (or 4)
+        assert np.allclose(a2, a, rtol=1e-9) and np.allclose(Q2[:8], Q[:8], atol=1e-8), np.abs(Q2 - Q).max(axis=1)
+    rp, ci = O.gen_rmat(16, 65536, 1500000, 99, a=0.7, b=0.12, c=0.12)
+    n, k = 65536, 30
+    x0 = np.ones(n)
+    a, b, Q, xn = O.lanczos(rp, ci, k, x0, q_colmajor=True)
+    assert max(abs(Q[0] @ Q[j]) for j in range(2, k)) > 1e-3           # the plain loop has lost orthogonality here
+    a1, b1, Q1, xn1 = O.lanczos_arnoldi(rp, ci, k, x0, every=1)
+    assert max(abs(Q1[0] @ Q1[j]) for j in range(2, k)) < 1e-9
+    R = O.referee_expm(rp, ci, k, x0, caps=(40.0,), reorth=1)
+    lam, V = O.eigen(a1, b1)
+    s = min(1.0, 40.0 / lam.max())
+    got = (V @ (np.exp(s * (lam - lam.max())) * (xn1 * V[0, :]))) @ Q1
+    assert np.abs(got - R["ans"][0]).max() <= 1e-10 * np.abs(R["ans"][0]).max()
