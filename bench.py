@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Lanczos iterations/sec + SpMV effective HBM GB/s on synthetic R-MAT graphs (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|er|er1m|c5]
 
 A "step" is one Lanczos iteration (serial/lib/lanczos.cc:21-53) on a graph already reshaped and resident in
 HBM; the timed region is exactly K iterations (lzx_lanczos_run), bracketed by a barrier and a device
@@ -36,6 +36,11 @@ WORKLOADS = {
            1 << 20, 20_000_000, 1234, 50),
     "c3": ("C3/C4: R-MAT scale 24 (a,b,c,d)=(.57,.19,.19,.05), endpoints >= n re-drawn, n=10,000,000, "
            "200M draws, seed 1234", "rmat", 24, 10_000_000, 200_000_000, 1234, 50),
+    # the uniform family north_star names beside R-MAT ("a 100 M-edge graph"): no hubs, every (row, column band) pair holds
+    # about one entry, so nothing can be summed before it crosses the two passes
+    "er": ("ER: Erdos-Renyi G(n, M) n=10,000,000, 100M draws (north_star's 100 M-edge graph), seed 1234", "er", 0,
+           10_000_000, 100_000_000, 1234, 50),
+    "er1m": ("ER: Erdos-Renyi n=1,000,000, 10M draws, seed 1234", "er", 0, 1_000_000, 10_000_000, 1234, 50),
     # 3.9e9 stored entries (> 2^32): every rank generates and keeps the whole graph (17 GB) and reshapes its own rows; fits
     # one MI355X too (about 100 iter/s there).  Use --no-cpu-baseline at N = 1: the host loop takes minutes per iteration.
     "c5": ("C5: R-MAT scale 27 (a,b,c,d)=(.57,.19,.19,.05), endpoints >= n re-drawn, n=100,000,000, 2G draws, "
@@ -191,7 +196,25 @@ def main():
         if eng is None:
             sys.exit(f"bench.py rank {rank}: could not build the engine (see stderr of the failing rank)")
         tune["single"] = timed(eng)
-        alt, _ = make_engine()
+        # The overlapped mode is asked for explicitly (over RCCL it is off by default until it has run on >= 2 GPUs).  What
+        # can go wrong there is an exception (handled below: every rank falls back) or a collective that never completes:
+        # for that a watchdog thread ends THIS process with a non-zero code (every rank has one; a rank that is not stuck
+        # itself gets stuck in the next collective and its own watchdog fires) -- the run fails fast and visibly instead of
+        # sitting in the driver's time limit.  Nothing is re-executed from a GPU process.
+        import threading
+        trial_done = threading.Event()
+
+        def watchdog(limit_s=float(os.environ.get("LZX_BENCH_TRIAL_LIMIT_S", "120"))):
+            if not trial_done.wait(limit_s):
+                print(f"[bench rank {rank}] the overlapped-exchange trial did not finish within {limit_s:.0f} s: giving up "
+                      f"(set overlap_exchange=0 to skip the trial)", file=sys.stderr, flush=True)
+                os._exit(17)
+
+        if os.environ.get("LZX_BENCH_SKIP_OVERLAP_TRIAL") == "1":
+            alt = None
+        else:
+            threading.Thread(target=watchdog, daemon=True).start()
+            alt, _ = make_engine(overlap_exchange=1, sparse_exchange=1)
         # a rank count / graph that does not qualify for the overlapped mode on some rank: nothing to compare
         if alt is not None and all_ok(bool(alt.info()["pb_entries"])):
             # the two-chunk exchange (second chunk sparse: grouped ncclSend / ncclRecv) has only ever run in-process
@@ -210,6 +233,7 @@ def main():
                     eng, alt = alt, None
         if alt is not None:
             alt.close()
+        trial_done.set()
     gi = eng.info()
 
     def barrier():

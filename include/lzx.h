@@ -204,13 +204,15 @@ int lzx_bench_spmv(lzx_handle h, uint32_t reps, double *avg_ms, double *min_ms);
  * bytes (rounded to 16; >= 256 MiB recommended), best of `reps`.  Results in GB/s (copy: bytes read + bytes written). */
 int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_gbs, double *copy_gbs);
 
-/* Options, to be set before the graph is handed over (the last two: any time no decomposition is in progress):
+/* Options, to be set before the graph is handed over (the last two: any time; setting one abandons a decomposition that
+ * was being advanced in chunks):
  *   "hub_entries"           x values of the highest-degree vertices staged in LDS by the SpMV (0 = none)
  *   "propagation_blocking"  1 / 0 force the two-pass blocked treatment of non-staged columns on / off
  *                           (default: on for graphs whose x does not fit the L2s); with it off the sliced-ELL
  *                           rows are summed in the reference's order and come out bit-identical to serial/
- *   "overlap_exchange"      several ranks: 1 / 0 allow / forbid the two-chunk all-gather that overlaps the blocked
- *                           SpMV (default: allowed)
+ *   "overlap_exchange"      several ranks: 1 / 0 ask for / forbid the two-chunk all-gather that overlaps the blocked
+ *                           SpMV (default: on for in-process groups; over RCCL only on request -- bench.py asks in its
+ *                           guarded tuning phase -- until it has run once on two or more physical GPUs)
  *   "sparse_exchange"       1 / 0: with the two-chunk exchange, send each peer only the entries of the second chunk its rows
  *                           reference (default 1)
  *   "exchange_fp32"         1: several ranks exchange the new Lanczos vector rounded to fp32 (half the bytes; one all-gather,

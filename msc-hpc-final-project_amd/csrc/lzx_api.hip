@@ -101,7 +101,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     // the two options that shape the LOOP, not the graph, may change between decompositions
     const bool loop_option = !strcmp(name, "reorthogonalise") || !strcmp(name, "basis_fp32");
     if (c->d_row_ptr && !loop_option) LZX_FAIL(LZX_ERR_STATE, "options must be set before the graph is handed over");
-    if (loop_option && c->k_prep) LZX_FAIL(LZX_ERR_STATE, "a prepared decomposition is in progress");
+    if (loop_option) c->k_prep = 0;   // a decomposition that was being advanced in chunks is abandoned (what it has done stays usable)
     if (!strcmp(name, "hub_entries")) c->hub_opt = value;
     else if (!strcmp(name, "propagation_blocking")) c->pb_opt = value;
     else if (!strcmp(name, "overlap_exchange")) c->overlap_opt = value;
@@ -1060,6 +1060,30 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
                 (void *)c->d_pb_lrow, (void *)c->d_sell_cols, (void *)c->d_v, (void *)c->d_xbuf, (void *)c->d_ybuf);
         fprintf(stderr, "[lzx trace] k_spmv %.4f ms  long_finish %.4f ms  pb_scatter %.4f ms  pb_gather(+finish) %.4f ms  (mean of %d)\n",
                 t[0], t[1], t[2], t[3], TR);
+        if (c->d_pb_gstamps) {
+            const u32 G = c->pb_gather_grid;
+            std::vector<unsigned long long> h(8 * (size_t)G);
+            LZX_HIP(hipMemcpy(h.data(), c->d_pb_gstamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull;
+            for (u32 w = 0; w < G; ++w) if (h[8 * w + 1]) t0 = std::min(t0, h[8 * w]);
+            std::vector<double> en, zr, sm, br, fd, rate;
+            double items = 0, vals = 0;
+            for (u32 w = 0; w < G; ++w) {
+                const unsigned long long *r = &h[8 * (size_t)w];
+                if (!r[1]) continue;
+                en.push_back((r[1] - t0) * 0.01); zr.push_back(r[2] * 0.01); sm.push_back(r[3] * 0.01); br.push_back(r[4] * 0.01); fd.push_back(r[5] * 0.01);
+                items += (double)r[6]; vals += (double)r[7];
+                if (r[3]) rate.push_back((double)r[7] * 10.0 / (r[3] * 0.01) * 1e-3);   // GB/s while streaming (wavefront 0's clock; group items: its own band)
+            }
+            auto srt = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); };
+            srt(en); srt(zr); srt(sm); srt(br); srt(fd); srt(rate);
+            auto pct = [](const std::vector<double> &v, double p) { return v.empty() ? 0.0 : v[(size_t)(p * (v.size() - 1))]; };
+            fprintf(stderr, "[lzx gstamps] gather: %zu workgroups, %.0f items, %.0f values | end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f\n", en.size(), items, vals,
+                    en.front(), pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), en.back());
+            fprintf(stderr, "[lzx gstamps]   wavefront 0, us per workgroup (p10 / p50 / p90): records+zeroing %.1f / %.1f / %.1f | streaming %.1f / %.1f / %.1f | barrier before fold %.1f / %.1f / %.1f | fold %.1f / %.1f / %.1f | GB/s per workgroup while streaming p50 %.1f\n",
+                    pct(zr, 0.1), pct(zr, 0.5), pct(zr, 0.9), pct(sm, 0.1), pct(sm, 0.5), pct(sm, 0.9), pct(br, 0.1), pct(br, 0.5), pct(br, 0.9),
+                    pct(fd, 0.1), pct(fd, 0.5), pct(fd, 0.9), pct(rate, 0.5));
+        }
         if (c->d_pb_stamps) {
             // per-workgroup time lines of the persistent passes (100 MHz ticks): when did workgroups start and end
             std::vector<unsigned long long> h(3 * 4096);

@@ -27,6 +27,8 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (NCCL >= 2.18 / the RCCL of ROCm 6+): a second communicator over the same ranks for the exchange stream
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, void *) = nullptr;
 };
 RcclApi g_rccl;
 
@@ -56,6 +58,7 @@ int rccl_load()
     SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *reinterpret_cast<void **>(&g_rccl.CommSplit) = dlsym(lib, "ncclCommSplit");   // may be absent: one communicator then
     g_rccl.lib = lib;
     return LZX_OK;
 }
@@ -95,6 +98,14 @@ extern "C" int lzx_comm_init_rank(lzx_handle c, const uint8_t id[128], int rank,
     c->comm_kind = 2;
     c->world = world;
     c->rank = rank;
+    // The exchange stream gets a communicator of its own: RCCL serialises the operations of ONE communicator in issue
+    // order whatever streams they are given, so the sparse send / receive group of chunk 1 (stream2) would otherwise
+    // queue behind -- or ahead of -- the two-double all-reduce of the main stream instead of overlapping it.
+    c->nccl_comm2 = nullptr;
+    if (g_rccl.CommSplit) {
+        ncclComm_t comm2 = nullptr;
+        if (g_rccl.CommSplit(comm, 0, rank, &comm2, nullptr) == ncclSuccess && comm2) c->nccl_comm2 = comm2;
+    }
     return LZX_OK;
 }
 
@@ -129,10 +140,11 @@ extern "C" int lzx_comm_init_local(lzx_handle *hs, int world)
 
 void lzx_comm_release(lzx_ctx *c)
 {
+    if (c->comm_kind == 2 && c->nccl_comm2 && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_comm2));
     if (c->comm_kind == 2 && c->nccl_comm && g_rccl.CommDestroy) {
         (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
     }
-    c->nccl_comm = nullptr;
+    c->nccl_comm = c->nccl_comm2 = nullptr;
     delete[] c->peers;
     c->peers = nullptr;
     c->comm_kind = 0;
@@ -141,6 +153,8 @@ void lzx_comm_release(lzx_ctx *c)
 }
 
 static hipStream_t pick(lzx_ctx *c, bool s2) { return s2 ? c->stream2 : c->stream; }
+// the communicator of the stream an operation is queued on (the exchange stream has its own when RCCL can split)
+static ncclComm_t pick_comm(lzx_ctx *c, bool s2) { return static_cast<ncclComm_t>(s2 && c->nccl_comm2 ? c->nccl_comm2 : c->nccl_comm); }
 
 // Everything queued so far on every handle's `from` stream happens before what is queued next on every handle's
 // `to` stream (all pairs, own handle included when the two streams differ).
@@ -209,8 +223,7 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
         return LZX_OK;
     }
     if (c0->comm_kind == 2) {
-        LZX_NCCL(g_rccl.AllGather(src_loc[0], dst_full[0], cnt, ncclDouble,
-                                  static_cast<ncclComm_t>(c0->nccl_comm), pick(c0, on_stream2)));
+        LZX_NCCL(g_rccl.AllGather(src_loc[0], dst_full[0], cnt, ncclDouble, pick_comm(c0, on_stream2), pick(c0, on_stream2)));
         return LZX_OK;
     }
     const int world = c0->world;
@@ -241,7 +254,7 @@ int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slic
     if (c0->comm_kind == 2) {
         lzx_ctx *c = c0;
         const int me = c->rank;
-        ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_comm);
+        ncclComm_t comm = pick_comm(c, true);
         LZX_TRY(lzx_launch_sx_pack(c, slice_loc[0], c->stream2));
         double *seg = c->d_xbuf + (size_t)world * c->xs0;
         const u32 own = c->sx_send_off[me + 1] - c->sx_send_off[me];
@@ -278,6 +291,42 @@ int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slic
         }
     }
     LZX_TRY(cross_barrier(cs, true));
+    return LZX_OK;
+}
+
+// One-off check when the graph is reshaped (RCCL transport): every rank derives by itself what it sends to and receives
+// from each peer in the sparse chunk (k_sx_mark + a scan) -- nothing is negotiated, so a disagreement would only show as
+// a grouped ncclSend / ncclRecv that never completes.  All ranks gather everybody's [send counts | receive counts] and
+// check EVERY pair (what p packs for q == what q expects from p): all of them reach the same verdict, so a mismatch is an
+// error on every rank at once (LZX_ERR_STATE), never a hang.
+int lzx_comm_check_sparse(lzx_ctx *c)
+{
+    if (c->comm_kind != 2 || !c->sparse) return LZX_OK;
+    const u32 world = (u32)c->world;
+    std::vector<u32> mine(2 * (size_t)world), all(2 * (size_t)world * world);
+    for (u32 p = 0; p < world; ++p) {
+        mine[p] = c->sx_send_off[p + 1] - c->sx_send_off[p];
+        mine[world + p] = c->sx_recv_off[p + 1] - c->sx_recv_off[p];
+    }
+    u32 *d = nullptr;
+    LZX_HIP(hipSetDevice(c->device));
+    LZX_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(u32) * (mine.size() + all.size())));
+    hipError_t e = hipMemcpyAsync(d, mine.data(), sizeof(u32) * mine.size(), hipMemcpyHostToDevice, c->stream);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess)
+        r = g_rccl.AllGather(d, d + mine.size(), mine.size(), ncclUint32, static_cast<ncclComm_t>(c->nccl_comm), c->stream);
+    if (e == hipSuccess && r == ncclSuccess)
+        e = hipMemcpyAsync(all.data(), d + mine.size(), sizeof(u32) * all.size(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (r != ncclSuccess) LZX_FAIL(LZX_ERR_COMM, "sparse exchange check: %s", g_rccl.GetErrorString(r));
+    LZX_HIP(e);
+    for (u32 p = 0; p < world; ++p)
+        for (u32 q = 0; q < world; ++q) {
+            const u32 sends = all[(size_t)p * 2 * world + q], expects = all[(size_t)q * 2 * world + world + p];
+            if (sends != expects)
+                LZX_FAIL(LZX_ERR_STATE, "sparse exchange: rank %u packs %u entries for rank %u, which expects %u", p, sends, q, expects);
+        }
     return LZX_OK;
 }
 

@@ -442,7 +442,11 @@ int lzx_graph_prepare(lzx_ctx *c)
     c->xs0 = c->xs;
     c->overlap = false;
     c->xfp32 = (world > 1 || c->force_multi) && c->xfp32_opt > 0;   // N4: fp32 exchange uses the single all-gather
-    if ((world > 1 || c->force_multi) && pb && c->overlap_opt != 0 && !c->xfp32) {
+    // (over RCCL only on request: the two-chunk exchange with its sparse second chunk -- a grouped ncclSend / ncclRecv on
+    //  the exchange stream -- has never run on two or more physical GPUs; bench.py asks for it in its guarded tuning
+    //  phase.  In-process groups take it by default: every form of it is covered there, tests/test_gpu_parity.py.)
+    const bool overlap_wanted = c->overlap_opt > 0 || (c->overlap_opt < 0 && c->comm_kind != 2);
+    if ((world > 1 || c->force_multi) && pb && overlap_wanted && !c->xfp32) {
         u32 x0 = round_up(std::max<u32>(c->xs / 8, (c->hub_real + world - 1) / world), LZX_PB_CB);
         if (x0 < c->xs) {
             c->xs0 = x0;
@@ -546,6 +550,8 @@ int lzx_graph_prepare(lzx_ctx *c)
 #undef SX_HIP
         c->sparse = true;
         c->xlen = (u64)world * c->xs0 + round_up((u32)c->xc1, LZX_SLICE) + LZX_TAIL;
+        rc = lzx_comm_check_sparse(c);   // RCCL: every pair of ranks agrees on what travels, or all of them fail here
+        if (rc != LZX_OK) { cleanup(); return rc; }
     }
 
     // ---- 2. this rank's rows ----

@@ -86,6 +86,7 @@ struct lzx_ctx {
     int comm_kind = 0;                 // 0 none, 1 local (one process, peers[]), 2 RCCL
     lzx_ctx **peers = nullptr;         // local mode: all handles, index = rank (owned by rank 0's array copy)
     void *nccl_comm = nullptr;
+    void *nccl_comm2 = nullptr;        // the exchange stream's own communicator (ncclCommSplit of nccl_comm), or null
 
     // ---- whole graph, caller's vertex order (device) ----
     u64 n = 0, nnz = 0, max_degree = 0;
@@ -201,6 +202,7 @@ struct lzx_ctx {
     u32 pb_qbase[4] = {0, 0, 0, 0};    // value each counter will have when its next launch starts
     unsigned long long *d_pb_stamps = nullptr;   // [3][4096] debug library, option pb_stamps: per-workgroup start / end ticks
     int64_t pb_stamps_opt = -1;
+    unsigned long long *d_pb_gstamps = nullptr;  // [pb_gather_grid][8] debug library, option pb_stamps: the product gather pass's sections
     int64_t tie_sort_opt = -1;         // blocked mode: ties of the degree ranking broken by staged-column count (debug knob; 0 = by id)
     int64_t item_opt = -1;             // entries per split-row item (debug knob; default LZX_ITEM)
     int64_t vec_per_cu_opt = -1;       // blocks per CU of the vector kernels (debug knob; default 8)
@@ -343,6 +345,7 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
 // own slice of the new vector) and the packed pieces land in the peers' d_xbuf behind chunk 0; on the exchange streams
 int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
 int lzx_launch_sx_pack(lzx_ctx *c, const double *slice_loc, hipStream_t st);
+int lzx_comm_check_sparse(lzx_ctx *c);   // RCCL: all ranks' send / receive counts of the sparse chunk agree pairwise, or LZX_ERR_STATE everywhere
 // N4: all-gather of the slices as fp32 into every handle's d_xbuf (converted back to fp64 there), main streams
 int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
 int lzx_launch_to_f32(lzx_ctx *c, const double *in, float *out, u64 count);

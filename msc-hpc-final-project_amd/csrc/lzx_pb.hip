@@ -553,11 +553,19 @@ __device__ __forceinline__ double wave_sum_pb(double v)
 // One WORKGROUP per item: its eight wavefronts take the item's 128-value blocks round-robin (so the workgroup reads 8
 // consecutive KiB at a time -- a few hundred sequential streams chip-wide instead of four thousand), each adding into
 // its own y tile; the tiles are folded in wavefront order.
+// STAMP (debug library, option pb_stamps): wavefront 0 of every workgroup keeps 100 MHz time stamps per section --
+// stamps[8 * workgroup ..]: start, end, ticks zeroing tiles + reading item records, ticks streaming, ticks in barriers
+// before the fold, ticks folding, items, values.
+template <bool STAMP>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
 k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *band_rep, const u32 *band_beg,
             const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
-            double *partials)
+            double *partials, unsigned long long *stamps)
 {
+    unsigned long long t_start = 0, t_mark = 0, t_zero = 0, t_stream = 0, t_bar = 0, t_fold = 0, n_vals = 0;
+    u32 n_it = 0;
+#define GSTAMP(acc) do { if (STAMP) { const unsigned long long t_ = wall_clock64(); acc += t_ - t_mark; t_mark = t_; } } while (0)
+    if (STAMP) t_start = t_mark = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
     constexpr u32 TILE = LZX_PB_RB + 8;                  // + spare slot for padding entries
@@ -581,6 +589,8 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
                 const u32 slots = rows * rep;
                 for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
                 __builtin_amdgcn_wave_barrier();
+                if (STAMP) { ++n_it; n_vals += end - beg; }
+                GSTAMP(t_zero);
                 const u32 blocks = (end - beg) / 128u;
                 u32 kb = 0;
                 for (; kb + 8 <= blocks; kb += 8) {
@@ -631,6 +641,7 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
                     atomicAdd(&ytile[ts[1]], tv[1]);
                 }
                 __builtin_amdgcn_wave_barrier();
+                GSTAMP(t_stream);
                 // fold: replicas in order; four rows per lane at a time, loads before stores
                 for (u32 j0 = lane; j0 < rows; j0 += 256) {
                     double vv[4], qq[4];
@@ -651,10 +662,12 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
                         }
                     }
                 }
+                GSTAMP(t_fold);
             }
             continue;
         }
         const u32 R = item.x, beg = item.y, end = item.z;
+        if (STAMP) { ++n_it; n_vals += end - beg; }
         const u32 row0 = band_row0[R], rows = band_row0[R + 1] - row0;
         if (rows == 1) {
             // one heavy row: plain strided sum (padding holds zeros), fixed reduction order
@@ -689,6 +702,7 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
         __syncthreads();                     // the previous item's fold is done with the tiles
         for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
         __builtin_amdgcn_wave_barrier();
+        GSTAMP(t_zero);
         // whole blocks of 128 values (an item begins on a block boundary of its band): lane l owns values 2 l, 2 l + 1
         // of its wavefront's blocks; eight blocks in flight per wavefront
         const u32 blocks = (end - beg) / 128u;
@@ -718,7 +732,9 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
         // the band's tail (< 128 values): 64 consecutive values per instruction, wavefront 0
         if (wv == 0)
             for (u32 i = beg + blocks * 128u + lane; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
+        GSTAMP(t_stream);
         __syncthreads();
+        GSTAMP(t_bar);
         // fold: wavefront tiles in order, replicas in order; every thread a few rows, loads before stores
         if (item.w == 0xffffffffu) {
             for (u32 j0 = tid; j0 < rows; j0 += 2 * LZX_PB_GATHER_BLOCK) {
@@ -749,7 +765,13 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
                 part[item.w + j] = y;
             }
         }
+        GSTAMP(t_fold);
     }
+    if (STAMP && tid == 0) {
+        unsigned long long *o = stamps + 8 * (size_t)blockIdx.x;
+        o[0] = t_start; o[1] = wall_clock64(); o[2] = t_zero; o[3] = t_stream; o[4] = t_bar; o[5] = t_fold; o[6] = n_it; o[7] = n_vals;
+    }
+#undef GSTAMP
     dot = wave_sum_pb(dot);
     __syncthreads();
     if (lane == 0) wsum[wv] = dot;
@@ -1326,6 +1348,7 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_seg);
     pb_free(c->d_pb_seg_begin);
     pb_free(c->d_pb_stamps);
+    pb_free(c->d_pb_gstamps);
     pb_free(c->d_pb_queue);
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
@@ -1995,6 +2018,12 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         LZX_HIP(hipStreamSynchronize(st));
     }
 #endif
+#ifdef LZX_DEBUG_KNOBS
+    if (c->pb_stamps_opt > 0 && c->pb_persist_opt <= 0) {   // per-workgroup section stamps of the product gather pass
+        LZX_TRY(pb_alloc(&c->d_pb_gstamps, 8 * (u64)c->pb_gather_grid));
+        LZX_HIP(hipMemsetAsync(c->d_pb_gstamps, 0, sizeof(unsigned long long) * 8 * c->pb_gather_grid, st));
+    }
+#endif
     {   // split rows (the first n_long64 local rows) that are also rows of a multi-item band
         std::vector<uint8_t> flag((size_t)c->n_long64 + 1, 0);
         for (size_t i = 0; i < multi.size(); i += 4)
@@ -2138,7 +2167,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     }
     if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);
-    LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather),
+    LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (c->phase_mask_opt & 8) {
         // experiment: scatter pass alone
@@ -2151,11 +2180,16 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         hipLaunchKernelGGL(gk, dim3(c->pb_gather_grid), dim3(block), lds2p, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_items2), c->d_pb_wg_begin, c->d_pb_lrow, c->d_pb_val, v, q_loc,
                            c->d_pb_part, partials, c->d_pb_stamps ? c->d_pb_stamps + 8192 : nullptr);
+    } else if (c->pb_stamps_opt > 0 && c->d_pb_gstamps) {
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_pb_gather<true>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
+                           reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,
+                           c->d_pb_val, v, q_loc, c->d_pb_part, partials, c->d_pb_gstamps);
 #endif
     } else
-    hipLaunchKernelGGL(k_pb_gather, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
+    hipLaunchKernelGGL(k_pb_gather<false>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,
-                       c->d_pb_val, v, q_loc, c->d_pb_part, partials);
+                       c->d_pb_val, v, q_loc, c->d_pb_part, partials, nullptr);
     if (c->pb_finish_grid)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, c->d_item_first,

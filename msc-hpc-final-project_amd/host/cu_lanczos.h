@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "adjMatrix.h"
 #include "device_graph.h"
@@ -42,7 +43,6 @@ T inner_prod(const T *const v, const T *const w, const U n) {
 
 template <typename T> class eigenDecomp;
 template <typename T> class lanczosDecomp;
-struct convergenceReport;
 template <typename U, typename V> void check_ans(lanczosDecomp<U> &, lanczosDecomp<V> &);
 
 // Timings of the device path of the last constructed decomposition (milliseconds).
@@ -54,11 +54,37 @@ struct lanczosTimings {
   unsigned gpus = 0;
 };
 
+// What the reference's other constructors and its open problems add to the four-argument form:
+//   arnoldi_every  serial/lib/lanczos.h:44-57's `bool arnoldi` (decompose_with_arnoldi, serial/lib/lanczos.cc:58-132) with its
+//                  hard-coded `reorthog_every_k {2}` (:71) as a parameter: when j % e == 0 and j > 2, A q_j is orthogonalised
+//                  against q_0 .. q_{j-2} before alpha_j is taken.  2 = the reference (which "does not give good results",
+//                  serial/tests/numerical_test_orthog.cc:3-4: orthogonality goes between two passes); 1 keeps the basis
+//                  orthogonal.  0 = off.
+//   adaptive_step  > 0 (device path): the decomposition is advanced in chunks of this many iterations and stops at the first
+//                  chunk whose answer y_k moved by less than adaptive_tol (relative 2-norm) -- the reference can only look at
+//                  a finished decomposition (parallel-final/lib/multiplyOut.cu:25-49; writeup section 11); here convergence
+//                  saves SpMVs.  get_krylov() is the dimension actually used afterwards.
+//   basis_fp32     the device-resident basis stored as fp32 (half the HBM; alpha / beta unchanged bit for bit).
+struct lanczosOptions {
+  unsigned arnoldi_every = 0;
+  unsigned adaptive_step = 0;
+  double adaptive_tol = 1e-10;
+  bool basis_fp32 = false;
+};
+
+struct convergenceReport {
+  unsigned k_used = 0;
+  bool converged = false;
+  std::vector<unsigned> k;          // dimensions evaluated
+  std::vector<double> rel_change;   // ||y_k - y_{k-step}|| / ||y_k|| (first entry: 1)
+};
+
 template <typename T>
 class lanczosDecomp {
  public:
   lanczosDecomp() = delete;
   lanczosDecomp(adjMatrix &adj, const unsigned krylov, T *starting_vec, bool cuda);
+  lanczosDecomp(adjMatrix &adj, const unsigned krylov, T *starting_vec, bool cuda, const lanczosOptions &opt);
   lanczosDecomp(lanczosDecomp &) = delete;
   lanczosDecomp &operator=(lanczosDecomp &) = delete;
   ~lanczosDecomp();
@@ -80,6 +106,13 @@ class lanczosDecomp {
   unsigned gpus() const { return graph ? static_cast<unsigned>(graph->ranks.size()) : 0; }
   // The host copy of the basis (layout above); a device decomposition downloads it on the first call.
   const T *basis() { ensure_host_basis(); return Q; }
+  // adaptive_step > 0: what the chunked run evaluated; iterations (= SpMVs) it actually ran
+  const convergenceReport &convergence() const { return adaptive; }
+  unsigned iterations_run() const { return iters_run; }
+  // Post-hoc orthonormalisation of the stored basis, the role of serial/lib/lanczos.cc:202-207 (LAPACKE_dgeqrf + dorgqr):
+  // Q <- the orthonormal factor of Q = Q'R, here by two modified Gram-Schmidt sweeps (R's diagonal positive; LAPACK's
+  // Householder form may flip the sign of a column).  A device decomposition brings its basis to the host first.
+  void reorthog();
 
   friend class eigenDecomp<T>;
   template <typename U> friend void multOut(lanczosDecomp<U> &, eigenDecomp<U> &, adjMatrix &, bool);
@@ -97,6 +130,11 @@ class lanczosDecomp {
   T *x = nullptr;      // starting vector          [n]
   T *ans = nullptr;    // e^A x once multOut ran   [n]
   T x_norm;
+  lanczosOptions opts;
+  convergenceReport adaptive;
+  unsigned iters_run = 0;
+  bool on_device_layout = false;       // Q (once on the host) holds k contiguous vectors rather than row-major n x k
+  bool basis_lost = false;             // the resident basis was overwritten and could not be brought to the host
   std::shared_ptr<deviceGraph> graph;  // device path: the adjMatrix's graph on the GPU(s); the basis is resident there
   lanczosTimings times;
 
@@ -105,5 +143,6 @@ class lanczosDecomp {
   static void evict_cb(void *self);     // another decomposition is about to overwrite the resident basis
 
   void decompose();     // CPU:    serial/lib/lanczos.cc:9-56 == parallel-final/lib/lanczos.cu:17-60
+  void decompose_with_arnoldi(unsigned every);   // CPU: serial/lib/lanczos.cc:58-132
   void cu_decompose();  // MI355X: replaces parallel-final/lib/cu_lanczos.cu:20-142
 };

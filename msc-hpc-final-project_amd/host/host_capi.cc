@@ -112,6 +112,45 @@ long host_adaptive_file(const char *path, unsigned kmax, unsigned step, double t
   }
 }
 
+// The pipeline with lanczosOptions: arnoldi_every (serial/lib/lanczos.h:44-57's fourth argument, generalised), adaptive_step /
+// adaptive_tol (the device decomposition stops when its answer has converged), basis_fp32.  Outputs as host_expm_file plus
+// info[0] = Krylov dimension used, info[1] = iterations actually run, info[2] = chunks evaluated, info[3] = converged;
+// changes[] receives up to `cap` relative changes.  reorthog != 0: L.reorthog() before multOut (serial/lib/lanczos.cc:202-207).
+long host_expm_options_file(const char *path, unsigned k, int cuda, int device_multout, unsigned arnoldi_every, unsigned adaptive_step,
+                            double adaptive_tol, int basis_fp32, int reorthog, double *ans, unsigned ans_len, double *alpha,
+                            double *beta, unsigned *info, double *changes, unsigned cap) {
+  try {
+    std::ifstream fs(path);
+    if (fs.fail()) { g_host_err = std::string("cannot open ") + path; return -1; }
+    unsigned n = 0, edges = 0;
+    fs >> n >> n >> edges;
+    adjMatrix A(n, edges, fs);
+    if (ans_len < n) { g_host_err = "answer buffer too small"; return -2; }
+    std::vector<double> x(n, 1.0);
+    lanczosOptions o;
+    o.arnoldi_every = arnoldi_every;
+    o.adaptive_step = adaptive_step;
+    o.adaptive_tol = adaptive_tol;
+    o.basis_fp32 = basis_fp32 != 0;
+    lanczosDecomp<double> L(A, k, x.data(), cuda != 0, o);
+    const unsigned ku = L.get_krylov();
+    if (alpha) std::copy(L.get_alpha(), L.get_alpha() + ku, alpha);
+    if (beta && ku > 1) std::copy(L.get_beta(), L.get_beta() + (ku - 1), beta);
+    if (reorthog) L.reorthog();
+    eigenDecomp<double> E(L);
+    if (cuda && device_multout) cu_multOut(L, E, A, true);
+    else multOut(L, E, A, cuda != 0);
+    std::copy(L.answer(), L.answer() + n, ans);
+    const convergenceReport &rep = L.convergence();
+    if (info) { info[0] = ku; info[1] = L.iterations_run(); info[2] = static_cast<unsigned>(rep.k.size()); info[3] = rep.converged; }
+    for (unsigned i = 0; i < std::min<unsigned>(cap, static_cast<unsigned>(rep.rel_change.size())); ++i) changes[i] = rep.rel_change[i];
+    return static_cast<long>(n);
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
 // Loader only: CSR of a graph file as the adjMatrix file constructor builds it.
 // row_offset[n+1], col_idx[2*E] (caller sizes them from the header); returns stored edges or < 0.
 long host_load_csr(const char *path, unsigned *row_offset, unsigned *col_idx, unsigned max_nnz) {

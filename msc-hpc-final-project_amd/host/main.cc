@@ -9,7 +9,10 @@
 //             but hard-wires file input, main.cu:57)
 //   -n N -b M generate a seeded Barabasi-Albert graph of minimum degree M
 //   -v        verbose: print the answer vector
-// Environment: FINAL_SKIP_SERIAL=1 skips the CPU run (large graphs), FINAL_DEVICE_MULTOUT=1 uses the
+// Environment: FINAL_ADAPTIVE_STEP=S [FINAL_ADAPTIVE_TOL=t, default 1e-10]: the device run advances in chunks of S iterations and
+// stops once the answer moved by less than t (K is then the upper limit; k_used is printed); FINAL_ARNOLDI=E: both runs
+// re-orthogonalise every E iterations (serial/lib/lanczos.cc:58-132; the reference's constant is 2);
+// FINAL_SKIP_SERIAL=1 skips the CPU run (large graphs), FINAL_DEVICE_MULTOUT=1 uses the
 // on-device back-projection (parallel-mult-on-card's cu_multOut) for the GPU column; LZX_DEVICES=all | N | a,b,c
 // spreads the device run over several GPUs from this one process (parallel-two-cards' model, any number of cards);
 // LZX_NO_CSR_CACHE=1, LZX_HOST_INGEST=1, LZX_PARSE_THREADS=T steer the loader (host/adjMatrix.h).
@@ -96,12 +99,17 @@ int main(int argc, char **argv) {
   std::vector<double> x(n, 1.0);
   const bool skip_serial = env_on("FINAL_SKIP_SERIAL");
 
+  lanczosOptions host_opt, dev_opt;
+  if (const char *v = std::getenv("FINAL_ARNOLDI")) host_opt.arnoldi_every = dev_opt.arnoldi_every = static_cast<unsigned>(std::atoi(v));
+  if (const char *v = std::getenv("FINAL_ADAPTIVE_STEP")) dev_opt.adaptive_step = static_cast<unsigned>(std::atoi(v));
+  if (const char *v = std::getenv("FINAL_ADAPTIVE_TOL")) dev_opt.adaptive_tol = std::atof(v);
+
   // ---- CPU ----
   double cpu_lanczos = 0, cpu_mult = 0, cpu_whole = 0;
   std::unique_ptr<lanczosDecomp<double>> L;
   if (!skip_serial) {
     stopwatch whole, t;
-    L = std::make_unique<lanczosDecomp<double>>(A, krylov_dim, x.data(), false);
+    L = std::make_unique<lanczosDecomp<double>>(A, krylov_dim, x.data(), false, host_opt);
     cpu_lanczos = t.seconds();
     eigenDecomp<double> E(*L);
     stopwatch tm;
@@ -113,8 +121,16 @@ int main(int argc, char **argv) {
 
   // ---- MI355X ----
   stopwatch gwhole, gt;
-  lanczosDecomp<double> cu_L(A, krylov_dim, x.data(), true);
+  lanczosDecomp<double> cu_L(A, krylov_dim, x.data(), true, dev_opt);
   const double gpu_lanczos = gt.seconds();
+  if (dev_opt.adaptive_step) {
+    const convergenceReport &rep = cu_L.convergence();
+    std::cout << "adaptive run: k_used = " << rep.k_used << " of at most " << krylov_dim << " (" << cu_L.iterations_run()
+              << " SpMVs run, " << (rep.converged ? "converged" : "NOT converged") << " at tolerance " << dev_opt.adaptive_tol
+              << "); relative changes:";
+    for (double c : rep.rel_change) std::cout << ' ' << c;
+    std::cout << "\n\n";
+  }
   eigenDecomp<double> cu_E(cu_L);
   stopwatch gm;
   if (env_on("FINAL_DEVICE_MULTOUT")) cu_multOut(cu_L, cu_E, A, true);
@@ -131,8 +147,8 @@ int main(int argc, char **argv) {
   row("Multiply Out", cpu_mult, gpu_mult, width);
   row("Entire algorithm", cpu_whole, gpu_whole, width);
   const lanczosTimings &tm = cu_L.timings();
-  std::cout << "device loop only: " << tm.loop_ms * 1e-3 << " s (" << krylov_dim / (tm.loop_ms * 1e-3) << " Lanczos iterations/s); "
-            << "SpMV " << tm.spmv_ms / krylov_dim << " ms each = " << (tm.spmv_ms > 0 ? tm.spmv_bytes / (tm.spmv_ms / krylov_dim) * 1e-6 : 0.0)
+  std::cout << "device loop only: " << tm.loop_ms * 1e-3 << " s (" << cu_L.iterations_run() / (tm.loop_ms * 1e-3) << " Lanczos iterations/s); "
+            << "SpMV " << tm.spmv_ms / cu_L.iterations_run() << " ms each = " << (tm.spmv_ms > 0 ? tm.spmv_bytes / (tm.spmv_ms / cu_L.iterations_run()) * 1e-6 : 0.0)
             << " GB/s of algorithmic bytes on " << tm.gpus << " GPU handle(s); graph upload + reshaping inside the constructor "
             << tm.setup_ms * 1e-3 << " s; basis download " << tm.fetch_ms * 1e-3 << " s\n";
 

@@ -40,6 +40,7 @@ void multOut(lanczosDecomp<T> &L, eigenDecomp<T> &E, adjMatrix &, bool Qtrans) {
       for (std::size_t i = 0; i < n; ++i) L.ans[i] += tj * q[i];
     }
   } else {
+    if (!L.Q) throw std::logic_error("multOut: Qtrans == false asks for a row-major basis, which a device decomposition does not produce (pass Qtrans = true)");
     for (std::size_t i = 0; i < n; ++i) {
       const T *row = L.Q + i * k;
       T s = 0;
@@ -85,6 +86,7 @@ convergenceReport multOutAdaptive(lanczosDecomp<T> &L, adjMatrix &, unsigned ste
     if (L.on_device()) {
       L.device_multout(t.data(), k, cur.data());
     } else if (Qtrans) {
+      L.ensure_host_basis();
       std::fill(cur.begin(), cur.end(), 0.0);
       for (unsigned j = 0; j < k; ++j) {
         const T *q = L.Q + static_cast<std::size_t>(j) * n;

@@ -24,12 +24,8 @@ void cu_multOut(lanczosDecomp<T> &, eigenDecomp<T> &, adjMatrix &, bool Qtrans =
 // y_k = ||x|| Q_k V_k e^{Lambda_k} V_k^T e_1 for k = step, 2*step, ... <= K, each from the leading k x k block of
 // the tridiagonal matrix, and stops at the first k whose answer moved by less than `tol` (relative 2-norm) from
 // the previous one.  L.ans holds y_{k_used} afterwards.  Uses the GPU-resident basis when L has one.
-struct convergenceReport {
-  unsigned k_used = 0;
-  bool converged = false;
-  std::vector<unsigned> k;          // dimensions evaluated
-  std::vector<double> rel_change;   // ||y_k - y_{k-step}|| / ||y_k|| (first entry: 1)
-};
+// (struct convergenceReport: cu_lanczos.h -- a decomposition constructed with lanczosOptions::adaptive_step carries one too,
+//  from a run that STOPPED at k_used instead of evaluating a finished decomposition.)
 
 template <typename T>
 convergenceReport multOutAdaptive(lanczosDecomp<T> &L, adjMatrix &A, unsigned step, double tol, bool Qtrans);

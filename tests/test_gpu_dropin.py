@@ -191,3 +191,61 @@ def test_bench_rehearses_the_multi_gpu_flow():
     tune = j["config"]["exchange_tuning_ms_per_iter"]
     assert {"single", "overlapped"} <= set(tune) and min(tune["single"], tune["overlapped"]) > 0
     assert j["value"] > 0 and j["config"]["lanczos_coefficients_finite"]
+
+
+def test_adaptive_stop_through_the_classes_and_the_cli(pkg, oracle, tmp_path):
+    """N3 proper in the drop-in layer: lanczosDecomp(A, k_max, x, cuda = true, lanczosOptions{adaptive_step, adaptive_tol})
+    advances the device decomposition in chunks and stops when the answer has converged -- fewer SpMVs than k_max, the
+    same answer as running k_used iterations in one go (the leading block of the same recurrence), within 1e-10 of the
+    oracle's e^A x; `final` prints k_used.  Also on three in-process handles, with the Arnoldi pass, and with the fp32 basis."""
+    O = oracle
+    pkg.lib()
+    H = ctypes.CDLL(os.path.join(HOST_DIR, "libmschpc_host.so"))
+    _u32p = ctypes.POINTER(ctypes.c_uint32)
+    H.host_expm_options_file.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint,
+                                         ctypes.c_double, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_uint, _f64p, _f64p, _u32p,
+                                         _f64p, ctypes.c_uint]
+    H.host_expm_options_file.restype = ctypes.c_long
+    H.host_last_error.restype = ctypes.c_char_p
+    rp, ci = O.gen_er(10000, 100000, 1234)               # BASELINE C1
+    n, kmax, step, tol = 10000, 50, 5, 1e-12
+    mtx = str(tmp_path / "c1.mtx")
+    O.write_mtx(mtx, n, rp, ci)
+    ans_ref = O.expm_action(rp, ci, kmax, np.ones(n))
+
+    def run(k, arnoldi=0, step_=0, fp32=0, devices=None):
+        if devices:
+            os.environ["LZX_DEVICES"] = devices
+        try:
+            ans, alpha, beta = np.zeros(n), np.zeros(k), np.zeros(k)
+            info, ch = np.zeros(4, dtype=np.uint32), np.zeros(16)
+            rc = H.host_expm_options_file(mtx.encode(), k, 1, 1, arnoldi, step_, tol, fp32, 0, ans.ctypes.data_as(_f64p), n,
+                                          alpha.ctypes.data_as(_f64p), beta.ctypes.data_as(_f64p), info.ctypes.data_as(_u32p),
+                                          ch.ctypes.data_as(_f64p), 16)
+            assert rc == n, H.host_last_error()
+            return ans, alpha, beta, info, ch
+        finally:
+            os.environ.pop("LZX_DEVICES", None)
+
+    ans, alpha, beta, info, ch = run(kmax, step_=step)
+    k_used, iters, chunks, conv = (int(v) for v in info)
+    assert conv == 1 and k_used < kmax and iters == k_used and chunks == k_used // step, info
+    assert ch[0] == 1.0 and ch[chunks - 1] <= tol < ch[chunks - 2]
+    assert np.abs(ans - ans_ref).max() <= 1e-10 * np.abs(ans_ref).max()
+    ans_one_go, a1, b1, info1, _ = run(k_used)
+    assert info1[0] == k_used and info1[1] == k_used
+    assert np.array_equal(alpha[:k_used], a1) and np.array_equal(beta[:k_used - 1], b1[:k_used - 1]) and np.array_equal(ans, ans_one_go)
+    print(f"adaptive device run on C1: k_used = {k_used} of {kmax}, changes {ch[:chunks]}")
+    # three handles on this GPU; the Arnoldi pass every iteration; the basis stored as fp32 (1e-6 then, not 1e-10)
+    ans3, _, _, info3, _ = run(kmax, step_=step, devices="0,0,0")
+    assert info3[0] == k_used and np.abs(ans3 - ans_ref).max() <= 1e-10 * np.abs(ans_ref).max()
+    ans_a, _, _, info_a, _ = run(kmax, arnoldi=1, step_=step)
+    assert info_a[3] == 1 and np.abs(ans_a - ans_ref).max() <= 1e-10 * np.abs(ans_ref).max()
+    ans_f, _, _, info_f, _ = run(kmax, step_=step, fp32=1)
+    assert 1e-10 < np.abs(ans_f - ans_ref).max() / np.abs(ans_ref).max() <= 1e-6
+    # the CLI
+    out = subprocess.run([os.path.join(HOST_DIR, "final"), "-f", mtx, "-k", str(kmax)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, FINAL_ADAPTIVE_STEP=str(step), FINAL_ADAPTIVE_TOL=str(tol)))
+    assert out.returncode == 0, out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("adaptive run: k_used")]
+    assert line and f"k_used = {k_used} of at most {kmax}" in line[0] and "converged" in line[0], out.stdout[-1500:]

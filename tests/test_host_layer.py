@@ -31,6 +31,10 @@ def host(pkg):
     H.host_gen_csr.restype = ctypes.c_long
     H.host_load_path.argtypes = [ctypes.c_char_p, _u32p, _u32p, ctypes.c_uint, _u32p]
     H.host_load_path.restype = ctypes.c_long
+    H.host_expm_options_file.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint,
+                                         ctypes.c_double, ctypes.c_int, ctypes.c_int, _f64p, ctypes.c_uint, _f64p, _f64p, _u32p,
+                                         _f64p, ctypes.c_uint]
+    H.host_expm_options_file.restype = ctypes.c_long
     return H
 
 
@@ -185,3 +189,34 @@ def test_self_loop_line_is_one_diagonal_entry(host, oracle, tmp_path, monkeypatc
     rc = host.host_expm_file(path.encode(), 3, 0, 0, p(ans, _f64p), 6, p(alpha, _f64p), p(beta, _f64p))
     assert rc == 6, host.host_last_error()
     assert np.isfinite(ans).all()
+
+
+def test_arnoldi_and_reorthog_in_the_class_layer(host, oracle, tmp_path):
+    """lanczosDecomp(A, k, x, cuda = false, lanczosOptions{arnoldi_every}) is serial/lib/lanczos.h:44-57's fourth-argument
+    constructor (decompose_with_arnoldi, serial/lib/lanczos.cc:58-132) with the hard-coded 2 as a parameter: identical
+    coefficients to the oracle's restatement (same operation order), for the reference's 2 and for 1.  reorthog()
+    (serial/lib/lanczos.cc:202-207) leaves the answer of a well-conditioned run where it was."""
+    O = oracle
+    rp, ci = O.gen_rmat(12, 3000, 40000, 3)
+    n, k = 3000, 16
+    mtx = str(tmp_path / "g.mtx")
+    O.write_mtx(mtx, n, rp, ci)
+    _, _, rp, ci = O.load_mtx(mtx)
+    x0 = np.ones(n)
+    for every in (1, 2):
+        a_ref, b_ref, Q_ref, xn = O.lanczos_arnoldi(rp, ci, k, x0, every=every)
+        ans, alpha, beta = np.zeros(n), np.zeros(k), np.zeros(k)
+        info = np.zeros(4, dtype=np.uint32)
+        rc = host.host_expm_options_file(mtx.encode(), k, 0, 0, every, 0, 0.0, 0, 0, p(ans, _f64p), n, p(alpha, _f64p), p(beta, _f64p),
+                                         p(info, _u32p), None, 0)
+        assert rc == n, host.host_last_error()
+        assert np.array_equal(alpha, a_ref) and np.array_equal(beta[:k - 1], b_ref), every
+        assert info[0] == k and info[1] == k
+        lam, V = O.eigen(a_ref, b_ref)
+        want = O.mult_out(np.ascontiguousarray(Q_ref.T), V, lam, xn)
+        assert np.abs(ans - want).max() <= 1e-12 * np.abs(want).max()
+    # reorthog() on the plain decomposition: Q was orthonormal to rounding already
+    plain, re = np.zeros(n), np.zeros(n)
+    assert host.host_expm_options_file(mtx.encode(), 10, 0, 0, 0, 0, 0.0, 0, 0, p(plain, _f64p), n, None, None, None, None, 0) == n
+    assert host.host_expm_options_file(mtx.encode(), 10, 0, 0, 0, 0, 0.0, 0, 1, p(re, _f64p), n, None, None, None, None, 0) == n
+    assert np.abs(re - plain).max() <= 1e-9 * np.abs(plain).max() and np.abs(re - plain).max() > 0

@@ -12,7 +12,9 @@ pkg = ge.load_pkg()
 if os.environ.get("LZX_PROBE_DBG_LIB"):   # A/B against another build of the debug library (same box, same job)
     pkg.DBG_LIB_PATH = os.environ["LZX_PROBE_DBG_LIB"]
 WORK = {"c2": (20, 1 << 20, 20_000_000), "c3": (24, 10_000_000, 200_000_000), "c2b": (20, 1_000_000, 20_000_000),
-        "big": (25, 30_000_000, 600_000_000), "c5": (27, 100_000_000, 2_000_000_000)}
+        "big": (25, 30_000_000, 600_000_000), "c5": (27, 100_000_000, 2_000_000_000),
+        # Erdos-Renyi (scale 0 = the ER generator): north_star's uniform family
+        "er": (0, 10_000_000, 100_000_000), "er1m": (0, 1_000_000, 10_000_000), "er4m": (0, 4_000_000, 40_000_000)}
 
 
 def run(name, opts_list, k=20):
@@ -20,7 +22,10 @@ def run(name, opts_list, k=20):
     for opts in opts_list:
         eng = pkg.Engine(0, **opts)
         t = time.time()
-        eng.gen_rmat(scale, n, draws, 1234)
+        if scale == 0:
+            eng.gen_er(n, draws, 1234)
+        else:
+            eng.gen_rmat(scale, n, draws, 1234)
         tg = time.time() - t
         gi = eng.info()
         avg, mn = eng.bench_spmv(20)
@@ -95,6 +100,9 @@ if __name__ == "__main__":
     if "pbdbg" in sets:
         opts = [dict(), dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, pb_target=16384),
                 dict(propagation_blocking=1, pb_run_align=4), dict(propagation_blocking=1, pb_run_align=16)]
+    if "er" in sets:   # the uniform family: blocked (every entry crosses as a value) vs plain gather, hub sizes, run formats
+        opts = [dict(), dict(propagation_blocking=0), dict(propagation_blocking=0, hub_entries=0), dict(propagation_blocking=1, hub_entries=1024),
+                dict(propagation_blocking=1, pb_reduce=0), dict(propagation_blocking=1, pb_column_band=8192)]
     if "pb" in sets:
         opts = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=8192),
                 dict(propagation_blocking=1, hub_entries=19000)]
