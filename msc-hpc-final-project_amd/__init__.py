@@ -19,6 +19,11 @@ DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
 PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "exchange_fp32",
                    "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32")
 
+# test-only shapes the product library accepts through lzx_test_set_shape (csrc/lzx_test_hooks.h): they select among code
+# paths the product contains (what large graphs get by themselves), so tests that force them still run liblzx.so
+SHAPE_OPTIONS = ("pb_reduce", "pb_target", "pb_unit", "pb_column_band", "pb_run_align", "pb_taper", "pb_group", "pb_group_force",
+                 "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1")
+
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -106,6 +111,8 @@ def _load(path: str, mode: int) -> ctypes.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    L.lzx_test_set_shape.restype = ctypes.c_int       # test hook, not in include/lzx.h
+    L.lzx_test_set_shape.argtypes = [_h, ctypes.c_char_p, ctypes.c_int64]
     return L
 
 
@@ -140,13 +147,17 @@ class Engine:
 
     def __init__(self, device: int = 0, **options):
         self.h = ctypes.c_void_p()
-        self.L = lib(debug=any(k not in PRODUCT_OPTIONS for k in options))
+        self.debug = any(k not in PRODUCT_OPTIONS and k not in SHAPE_OPTIONS for k in options)   # experiment knobs: liblzx_dbg.so
+        self.L = lib(debug=self.debug)
         _check(self.L.lzx_create(ctypes.byref(self.h), device), "lzx_create", self.L)
         for k, v in options.items():
             self.set_option(k, v)
         self.n = 0
 
     def set_option(self, name: str, value: int):
+        if name in SHAPE_OPTIONS and not self.debug:
+            _check(self.L.lzx_test_set_shape(self.h, name.encode(), int(value)), f"lzx_test_set_shape({name})", self.L)
+            return
         _check(self.L.lzx_set_option(self.h, name.encode(), int(value)), f"lzx_set_option({name})", self.L)
 
     def close(self):

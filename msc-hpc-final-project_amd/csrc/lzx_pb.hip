@@ -1780,6 +1780,27 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         for (u32 r = 0; r < nruns; ++r)
             if (fm[r]) red_entries += (r + 1 < nruns ? rs[r + 1] : (u32)total) - rs[r];
     }
+#ifdef LZX_DEBUG_KNOBS
+    if (getenv("LZX_PB_STATS")) {   // where the bytes of the tables go
+        std::vector<u32> rs;
+        std::vector<uint8_t> fm(nruns);
+        LZX_TRY(pb_download(st, d_runstart, nruns, rs));
+        LZX_HIP(hipMemcpy(fm.data(), d_fmt, nruns, hipMemcpyDeviceToHost));
+        u64 nred = 0, npl = 0, pl_entries = 0, pl_pad8 = 0;
+        for (u32 r = 0; r < nruns; ++r) {
+            const u32 rl = (r + 1 < nruns ? rs[r + 1] : (u32)total) - rs[r];
+            if (fm[r]) ++nred; else { ++npl; pl_entries += rl; pl_pad8 += (rl + 7u) & ~7u; }
+        }
+        std::vector<u32> se;
+        LZX_TRY(pb_download(st, d_step_excl, (size_t)nsteps + 1, se));
+        fprintf(stderr, "[lzx pb stats] entries %llu: reduced %llu in %llu runs -> %u steps = %llu padded entries (%.1f %% padding), %u pieces; "
+                "plain %llu in %llu runs -> %llu padded to 8; values incl. run alignment %llu (quads %llu); row bands %u, column bands %u, runs %u\n",
+                (unsigned long long)total, (unsigned long long)red_entries, (unsigned long long)nred, nsteps, (unsigned long long)epad_total,
+                100.0 * ((double)epad_total - (double)red_entries) / std::max<double>(1.0, (double)epad_total), nsteps ? se[nsteps] : 0u,
+                (unsigned long long)pl_entries, (unsigned long long)npl, (unsigned long long)pl_pad8, (unsigned long long)len,
+                (unsigned long long)nquads, nr, nb, nruns);
+    }
+#endif
     LZX_HIP(hipStreamSynchronize(st));
     ar.drop(d_sorted); ar.drop(d_runid); ar.drop(d_runstart); ar.drop(d_estart); ar.drop(d_fmt); ar.drop(d_vpos);
     ar.drop(d_rrow); ar.drop(d_step_run); ar.drop(d_step_excl);

@@ -1,0 +1,13 @@
+// lzx_test_hooks.h -- test-only entry of liblzx.so (NOT part of the boundary in include/lzx.h; the drop-in classes never call it).
+// Forces the table shapes that large graphs get by themselves onto small test graphs, so that tests/ exercise the product
+// library's own kernels in every shape: "pb_reduce" (minimum run length of a reduced run; 0 = every run plain), "pb_target"
+// (values per gather item), "pb_unit" (entries per scatter unit), "pb_column_band" (8192 | 16384), "pb_run_align", "pb_taper",
+// "pb_group" / "pb_group_force" (small row bands gathered one wavefront each), "narrow_slices", "tie_sort", "long_row",
+// "item_len", and "exchange_at_world_1" (a 1-rank RCCL communicator runs the several-rank loop, collectives included).
+#pragma once
+#include <stdint.h>
+#include "lzx.h"
+#ifdef __cplusplus
+extern "C"
+#endif
+int lzx_test_set_shape(lzx_handle h, const char *name, int64_t value);

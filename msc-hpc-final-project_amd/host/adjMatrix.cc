@@ -168,7 +168,7 @@ void adjMatrix::build_from_text(const std::string &text) {
     cut[t] = p;
   }
   std::vector<std::vector<unsigned>> ps(threads), pd(threads);
-  std::vector<int> bad(threads, 0);
+  std::vector<int> bad(threads, 0), odd(threads, 0);   // odd: the piece ended between the two numbers of a pair
   auto parse = [&](unsigned t) {
     const char *p = base + cut[t], *end = base + cut[t + 1];
     std::vector<unsigned> &s = ps[t], &d = pd[t];
@@ -183,8 +183,9 @@ void adjMatrix::build_from_text(const std::string &text) {
       return true;
     };
     std::uint64_t col, row;
-    while (next(col) && next(row)) {
-      if (col == 0 || row == 0 || col > n || row > n) { bad[t] = 1; return; }
+    while (next(col)) {
+      if (!next(row)) { odd[t] = 1; break; }
+      if (col == 0 || row == 0 || col > n || row > n) { bad[t] = 1; return; }   // pairs behind a bad one are never wanted
       s.push_back(static_cast<unsigned>(row - 1));   // files are 1-indexed
       d.push_back(static_cast<unsigned>(col - 1));
     }
@@ -194,15 +195,29 @@ void adjMatrix::build_from_text(const std::string &text) {
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < threads; ++t) pool.emplace_back(parse, t);
     for (auto &th : pool) th.join();
+    // The reference reads `f >> col >> row` as one token stream (parallel-final/lib/adjMatrix.cc:29-31): a file whose
+    // pairs are not one per line can have a pair straddle a cut.  Then the pieces pair differently from the stream:
+    // read it again as ONE piece.
+    bool straddles = false;
+    for (unsigned t = 0; t + 1 < threads; ++t) straddles = straddles || odd[t];
+    if (straddles) {
+      for (unsigned t = 0; t < threads; ++t) { ps[t].clear(); pd[t].clear(); bad[t] = odd[t] = 0; }
+      cut.assign(2, len);
+      cut[0] = 0;
+      threads = 1;
+      parse(0);
+    }
   }
   // join in order, up to the declared edge count (a short file keeps what was read; the reference reads garbage)
   std::vector<unsigned> src, dst;
   src.reserve(edge_count);
   dst.reserve(edge_count);
   for (unsigned t = 0; t < threads && src.size() < edge_count; ++t) {
-    const std::size_t take = std::min<std::size_t>(ps[t].size(), edge_count - src.size());
-    // an out-of-range id only counts when it lies among the pairs that are actually taken
-    if (bad[t] && take == ps[t].size()) throw std::runtime_error("adjMatrix: vertex id out of range");
+    const std::size_t want = edge_count - src.size();
+    const std::size_t take = std::min<std::size_t>(ps[t].size(), want);
+    // an out-of-range id only counts when it lies among the pairs that are actually taken: the bad pair is the one behind
+    // the ps[t].size() good ones of its piece
+    if (bad[t] && want > ps[t].size()) throw std::runtime_error("adjMatrix: vertex id out of range");
     src.insert(src.end(), ps[t].begin(), ps[t].begin() + take);
     dst.insert(dst.end(), pd[t].begin(), pd[t].begin() + take);
     std::vector<unsigned>().swap(ps[t]);
@@ -258,6 +273,10 @@ adjMatrix adjMatrix::load(const std::string &path) {
         g.col_idx = new unsigned[std::max<std::size_t>(h.nnz, 1)];
         ok = std::fread(g.row_offset, sizeof(unsigned), static_cast<std::size_t>(h.n) + 1, f) == static_cast<std::size_t>(h.n) + 1 &&
              std::fread(g.col_idx, sizeof(unsigned), h.nnz, f) == h.nnz && g.row_offset[h.n] == h.nnz;
+        // a side-car is only trusted as far as it can be checked: offsets ascending from 0, every column a vertex
+        if (ok) ok = g.row_offset[0] == 0;
+        for (std::size_t i = 0; ok && i < h.n; ++i) ok = g.row_offset[i] <= g.row_offset[i + 1];
+        for (std::size_t i = 0; ok && i < h.nnz; ++i) ok = g.col_idx[i] < h.n;
       }
       std::fclose(f);
       if (ok) {

@@ -271,12 +271,21 @@ def referee_lib():
         so = os.path.join(_HERE, "libreferee.so")
         if not os.path.exists(so):
             subprocess.check_call(["make", "-s", "-C", _HERE, "referee"])
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle threads sleep instead of spinning on a shared CPU
         R = ctypes.CDLL(so)
         R.ref_expm_ld.argtypes = [ctypes.c_uint64, _u64p, _u32p, ctypes.c_uint32, _f64p, ctypes.c_int, ctypes.c_uint32,
                                   _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
         R.ref_expm_ld.restype = ctypes.c_int
         R.ref_spmv_ld.argtypes = [ctypes.c_uint64, _u64p, _u32p, _f64p, _f64p]
         R.ref_spmv_ld.restype = ctypes.c_int
+        R.ref_set_threads.argtypes = [ctypes.c_int]
+        R.ref_set_threads.restype = None
+        # the job's CPU share, not the machine's thread count (a GPU box shows 256 hardware threads and grants ~16)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        R.ref_set_threads(int(os.environ.get("LZX_REFEREE_THREADS", min(16, avail))))
         _REFEREE = R
     return _REFEREE
 

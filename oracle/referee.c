@@ -24,7 +24,22 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 typedef long double ld;
+
+/* A GPU box hands a job a CPU share, not the machine: 256 hardware threads are visible, about 16 are ours, and an OpenMP
+ * team of 256 spinning at every barrier then crawls.  The caller says how many threads to use (oracle.py: at most 16). */
+void ref_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 #define REF_CHUNK 65536u
 

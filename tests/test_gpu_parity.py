@@ -88,6 +88,24 @@ def check_recurrence(O, rp, ci, a, b, Q, name):
         assert abs(np.linalg.norm(Q[j]) - 1.0) <= 1e-13, (name, j)
 
 
+def test_forced_shapes_run_the_product_library(pkg):
+    """every mode of MODES -- the forced run formats, band / item / unit sizes, slice classes and
+    gather groups -- is served by liblzx.so itself through its test-only entry lzx_test_set_shape (csrc/lzx_test_hooks.h),
+    so the parity tests below meet the oracle with the machine code the bench runs; only experiment knobs select
+    liblzx_dbg.so."""
+    for mode in MODES + [dict(exchange_at_world_1=1)]:
+        eng = pkg.Engine(0, **mode)
+        assert eng.L is pkg.lib() and not eng.debug, mode
+        eng.close()
+    eng = pkg.Engine(0, phase_mask=3)
+    assert eng.debug and eng.L is pkg.lib(debug=True)
+    eng.close()
+    eng = pkg.Engine(0)
+    with pytest.raises(pkg.LzxError):
+        eng.set_option("phase_mask", 3)          # the product library does not know experiment knobs
+    eng.close()
+
+
 def test_spmv_matches_oracle(oracle, engine_factory):
     O = oracle
     rng = np.random.default_rng(1234)

@@ -20,13 +20,24 @@ def _protocol(O, eng, rp, ci, n, k, name, small_ks, want_q):
     """engine and oracle against the referee at k and at the prefixes small_ks (a k'-step decomposition is the prefix of a
     k-step one).  Returns the printed table rows."""
     from test_gpu_parity import REL_INF_TOL, rel_inf, shift_weights
+    import sys
+    import time
+
+    def say(msg):          # a long CPU phase must not look like a hang to the GPU box's silence guard
+        print(f"[{name} {time.strftime('%H:%M:%S')}] {msg}", flush=True)
+        sys.stderr.write(".")
+        sys.stderr.flush()
+
     x0 = np.ones(n)
+    say(f"oracle: {k} iterations of serial/'s loop on one host thread")
     a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, x0, q_colmajor=True)
+    say("engine")
     a, b, Q, xn, st = eng.lanczos(x0, k, want_q=want_q)
     assert xn == xn_ref and st["iters"] == k and np.isfinite(a).all() and np.isfinite(b).all()
     rows = []
     R0 = None
     for kk in list(small_ks) + [k]:
+        say(f"referee, k = {kk}")
         R = R0 = O.referee_expm(rp, ci, kk, x0, caps=CAPS, reorth=0)
         for ci_, cap in enumerate((None, 40.0)):
             ref = R["ans"][ci_]
@@ -46,6 +57,7 @@ def _protocol(O, eng, rp, ci, n, k, name, small_ks, want_q):
     if k >= 50:
         # the referee is accurate enough to judge: with full re-orthogonalisation (a stand-in for exact-arithmetic
         # Lanczos) it gives the same answer to well below 1e-10
+        say("referee with full re-orthogonalisation")
         R1 = O.referee_expm(rp, ci, k, x0, caps=CAPS, reorth=1)
         for ci_ in range(2):
             own = rel_inf(R0["ans"][ci_], R1["ans"][ci_])

@@ -173,6 +173,57 @@ def test_parallel_parser_and_cache_match_the_sequential_loader(host, oracle, tmp
     assert c[0] == 0
 
 
+def test_parser_token_stream_semantics(host, oracle, tmp_path, monkeypatch):
+    """The reference reads `f >> col >> row` as ONE token stream (parallel-final/lib/adjMatrix.cc:29-31): line structure
+    means nothing.  A large file with three numbers per line makes pairs straddle the parser's cuts: the pieces then
+    pair differently from the stream and the loader must notice and read it as one piece.  An out-of-range
+    pair directly behind the declared edge count is not an error (it is never read), one inside it is."""
+    O = oracle
+    n = 60000
+    rp, ci = O.gen_rmat(16, n, 400000, 99)
+    path = str(tmp_path / "ref.mtx")
+    O.write_mtx(path, n, rp, ci)
+    tok = open(path).read().split()
+    body = tok[3:]
+    odd = str(tmp_path / "three_per_line.mtx")
+    with open(odd, "w") as f:
+        f.write(" ".join(tok[:3]) + "\n")
+        for i in range(0, len(body), 3):
+            f.write(" ".join(body[i:i + 3]) + "\n")
+    assert os.path.getsize(odd) > (1 << 20)
+    monkeypatch.setenv("LZX_NO_CSR_CACHE", "1")
+    monkeypatch.setenv("LZX_PARSE_THREADS", "7")
+    ro, cj, info = _load_path(host, odd, n, len(ci) + 8)
+    assert info[2] == 1                                 # fell back to one piece
+    assert np.array_equal(ro, rp.astype(np.uint32)) and np.array_equal(cj, ci)
+    # E good pairs, then a pair naming vertex n + 5: beyond the declared count, never read
+    tail = str(tmp_path / "bad_tail.mtx")
+    write_pairs(tail, 6, np.array([[2, 1], [5, 4], [6, 1]]))
+    with open(tail, "a") as f:
+        f.write("11 3\n")
+    ro, cj, info = _load_path(host, tail, 6, 16)
+    assert info[3] == 6
+    inside = str(tmp_path / "bad_inside.mtx")
+    write_pairs(inside, 6, np.array([[2, 1], [11, 3], [6, 1]]))
+    ro2 = np.zeros(7, dtype=np.uint32)
+    ci2 = np.zeros(16, dtype=np.uint32)
+    assert host.host_load_path(inside.encode(), p(ro2, _u32p), p(ci2, _u32p), 16, None) < 0
+    assert b"out of range" in host.host_last_error()
+    # a side-car whose columns are not vertices is not trusted: the text is parsed again
+    monkeypatch.delenv("LZX_NO_CSR_CACHE")
+    good = str(tmp_path / "cached.mtx")
+    write_pairs(good, 6, np.array([[2, 1], [5, 4], [6, 1]]))
+    ro_a, ci_a, ia = _load_path(host, good, 6, 16)
+    assert ia[0] == 0 and os.path.exists(good + ".lzxcsr")
+    raw = bytearray(open(good + ".lzxcsr", "rb").read())
+    raw[-4:] = (77).to_bytes(4, "little")               # last column index := 77
+    st = os.stat(good)
+    open(good + ".lzxcsr", "wb").write(raw)
+    os.utime(good, ns=(st.st_atime_ns, st.st_mtime_ns))
+    ro_b, ci_b, ib = _load_path(host, good, 6, 16)
+    assert ib[0] == 0 and np.array_equal(ro_b, ro_a) and np.array_equal(ci_b, ci_a)
+
+
 def test_self_loop_line_is_one_diagonal_entry(host, oracle, tmp_path, monkeypatch):
     """A `r r` line: the reference's std::set holds the key once, so the row gets ONE diagonal entry and
     row_offset[n] is odd (2 * edge_count would be one short / one over: ADVICE r1)."""
