@@ -354,6 +354,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
             LZX_HIP(hipSetDevice(c->device));
             c->iso_on = lazy && c->iso_opt != 0;
             c->iso_filled = false;
+            c->iso_cols_filled = 1;
             c->basis_u = lazy && c->basis_u_opt != 0;
             // columns 1.. are written by the loop up to rows_live only; with several ranks the exchanged prefix may reach
             // one slice further (into rows without an edge, which nobody reads): keep that slice clean
@@ -403,6 +404,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
     // One rank in blocked mode (whose sums are already ordered differently from the reference's) takes the same form:
     // it saves k_scale's pass over v and a launch; in plain mode one rank keeps the reference's order bit for bit.
     const bool lazy = loop_is_lazy(c0);
+    const bool mail_ok = multi && lzx_comm_mail_usable(cs);
     // timing marks on every 4th iteration (every one when k is small); the sums below are scaled to all iterations run
     const u32 every = c0->marks_every_opt > 0 ? (u32)c0->marks_every_opt : (k >= 8 ? 4u : 1u);
     for (u32 j = j0; lazy && j < j1; ++j) {
@@ -425,7 +427,11 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
         }
         LZX_TRY(mk.tick(CAT_SPMV));
         u32 np2 = 0;
-        if (multi) {
+        const bool mail = multi && mail_ok;
+        if (mail) {
+            // in-process group: each rank's pair goes straight into every peer's mailbox (one barrier, no copies)
+            LZX_TRY(lzx_comm_mail_reduce2(cs, j & 1u, first));
+        } else if (multi) {
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
                 // [u_j . w, ||u_j||^2] of this rank (the second from the previous iteration's k_lazy_update)
@@ -453,8 +459,10 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
                                                      lzx_spmv_partials(c), p_in, first ? 0 : c->np2_last, first ? 1 : 0, c->d_alpha + j,
                                                      first ? nullptr : c->d_beta + (j - 1), q_store, u_store, p_out, &np2, pdiv, f_store));
             else
-            LZX_TRY(lzx_launch_lazy_update(c, c->d_v, c->rows_live, uj, first ? nullptr : basis_col(c, j - 1), c->d_scal + 0, first ? 1 : 0,
-                                           c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), q_store, u_store, c->d_partials2, &np2, pdiv, f_store));
+            LZX_TRY(lzx_launch_lazy_update(c, c->d_v, c->rows_live, uj, first ? nullptr : basis_col(c, j - 1),
+                                           mail ? c->d_mail + (size_t)(j & 1u) * 64 * 2 : c->d_scal + 0, first ? 1 : 0,
+                                           c->d_alpha + j, first ? nullptr : c->d_beta + (j - 1), q_store, u_store, c->d_partials2, &np2, pdiv, f_store,
+                                           mail ? (u32)cs.size() : 0u));
             c->np2_last = np2;
         }
         LZX_TRY(mk.tick(CAT_VEC));
@@ -687,7 +695,7 @@ static int lanczos_fetch(std::vector<lzx_ctx *> &cs, u32 k, double *alpha, doubl
     if (Q) {
         // rows without an edge are kept as scalars times q_0 by the lazy loop: written out once somebody wants the basis
         for (lzx_ctx *c : cs) {
-            if (!c->iso_on || c->iso_filled) continue;
+            if (!c->iso_on || c->iso_cols_filled >= c->k_last) continue;   // (a decomposition advanced in chunks: the new columns)
             LZX_HIP(hipSetDevice(c->device));
             LZX_TRY(lzx_launch_iso_fill(c, c->k_last));
             c->iso_filled = true;

@@ -125,14 +125,29 @@ extern "C" int lzx_comm_init_local(lzx_handle *hs, int world)
         c->world = world;
         c->rank = p;
         // peers on other GPUs: let copies go straight over xGMI where the platform allows it
+        c->mail_ok = world <= 64;
         for (int q = 0; q < world; ++q) {
             if (hs[q]->device == c->device) continue;
             (void)hipSetDevice(c->device);
             int can = 0;
+            bool ok = false;
             if (hipDeviceCanAccessPeer(&can, c->device, hs[q]->device) == hipSuccess && can) {
                 hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                if (!ok) (void)hipGetLastError();
             }
+            if (!ok) c->mail_ok = false;   // its kernels cannot store into that peer's mailbox
+        }
+    }
+    // the mailboxes of the two-double reduction (lzx_internal.h: d_mail); without them the group reduces through copies
+    for (int p = 0; p < world; ++p) {
+        lzx_ctx *c = hs[p];
+        (void)hipSetDevice(c->device);
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_mail), sizeof(double) * 2 * 64 * 2) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_mail = nullptr;
+        } else {
+            (void)hipMemset(c->d_mail, 0, sizeof(double) * 2 * 64 * 2);
         }
     }
     return LZX_OK;
@@ -145,6 +160,9 @@ void lzx_comm_release(lzx_ctx *c)
         (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
     }
     c->nccl_comm = c->nccl_comm2 = nullptr;
+    if (c->d_mail) (void)hipFree(c->d_mail);
+    c->d_mail = nullptr;
+    c->mail_ok = false;
     delete[] c->peers;
     c->peers = nullptr;
     c->comm_kind = 0;
@@ -175,6 +193,29 @@ int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream
 
 // Make every stream in cs wait for everything queued so far on every other stream in cs.
 static int cross_barrier(std::vector<lzx_ctx *> &cs, bool s2 = false) { return lzx_comm_order(cs, s2, s2); }
+
+bool lzx_comm_mail_usable(std::vector<lzx_ctx *> &cs)
+{
+    if (cs.empty() || cs[0]->comm_kind != 1 || (int)cs.size() != cs[0]->world) return false;
+    for (lzx_ctx *c : cs)
+        if (!c->mail_ok || !c->d_mail) return false;
+    return true;
+}
+
+// Every handle's reduce kernel writes [u_j . w, ||u_j||^2] of its rank into slot [rank] of EVERY handle's mailbox of this
+// parity; one cross-handle barrier later every handle's vector kernel may read its own mailbox.
+int lzx_comm_mail_reduce2(std::vector<lzx_ctx *> &cs, u32 parity, bool first)
+{
+    const u32 world = (u32)cs.size();
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        MailPeers mp;
+        for (u32 q = 0; q < 64; ++q) mp.slot[q] = q < world ? cs[q]->d_mail + ((size_t)parity * 64 + (size_t)c->rank) * 2 : nullptr;
+        LZX_TRY(lzx_launch_reduce2_mail(c, c->d_partials, lzx_spmv_partials(c), c->d_partials2, first ? 0 : c->np2_last, mp, world));
+    }
+    return cross_barrier(cs);
+}
+
 
 __global__ void k_sum_ranks_n(const double *vals, int world, u32 count, double *out)
 {

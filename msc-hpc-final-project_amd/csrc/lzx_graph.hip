@@ -38,6 +38,7 @@ static void dev_free(T *&p)
 
 int lzx_graph_release(lzx_ctx *c)
 {
+    c->iso_cols_filled = 1;
     c->iso_on = c->iso_filled = c->basis_u = false;   // the factored rows belong to a decomposition on the old graph
 
     dev_free(c->d_row_ptr);

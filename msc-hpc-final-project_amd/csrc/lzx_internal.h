@@ -86,6 +86,12 @@ struct lzx_ctx {
     int comm_kind = 0;                 // 0 none, 1 local (one process, peers[]), 2 RCCL
     lzx_ctx **peers = nullptr;         // local mode: all handles, index = rank (owned by rank 0's array copy)
     void *nccl_comm = nullptr;
+    // in-process groups: the two-double reduction of the lazy loop through a peer-written mailbox -- every handle's reduce
+    // kernel stores its [D, B] straight into slot [rank] of every peer's mailbox, the consumer (k_lazy_update) adds the
+    // world pairs in rank order: one cross-handle barrier per iteration, no copies, no extra kernel.  Two mailboxes used
+    // alternately (iteration parity): a fast handle's next write cannot overtake a slow handle's read.
+    double *d_mail = nullptr;          // [2][64][2]
+    bool mail_ok = false;              // every peer's mailbox can be written from this handle's GPU
     void *nccl_comm2 = nullptr;        // the exchange stream's own communicator (ncclCommSplit of nccl_comm), or null
 
     // ---- whole graph, caller's vertex order (device) ----
@@ -234,7 +240,8 @@ struct lzx_ctx {
     bool basis_u = false;
     int64_t basis_u_opt = -1;          // debug knob unnormalised_basis: 0 = columns hold q_j, u_j alternates between d_u[0 / 1]
     bool iso_on = false;               // the last prepared decomposition runs in that form
-    bool iso_filled = false;           // ... and its basis columns 1.. have been materialised for those rows
+    bool iso_filled = false;           // ... and some of its basis columns have been materialised for those rows (a host fetch)
+    u32 iso_cols_filled = 1;           // columns [1, iso_cols_filled) are; column 0 (q_0) always is
     double *d_iso = nullptr;           // [2 k_cap + 4]: c_j at [j], d_j (the same for the unnormalised u_j) at [k_cap + 1 + j]; last: sum of q_0[i]^2 over those rows
     u32 iso_cap = 0;
     int64_t iso_opt = -1;              // debug knob isolated_rows: 0 = elementwise like every other row
@@ -306,11 +313,13 @@ int lzx_launch_spmv(lzx_ctx *c, const SpmvLaunch &a);
 u32 lzx_spmv_partials(const lzx_ctx *c);
 int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, int do_sqrt);
 int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, double *out2);
+struct MailPeers { double *slot[64]; };   // where this handle's pair goes in every peer's mailbox (parity applied)
+int lzx_launch_reduce2_mail(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, const MailPeers &peers, u32 world);
 int lzx_launch_iso_prepare(lzx_ctx *c, u32 k);                       // sum of squares of q_0 over the rows without an edge, c_0 = d_0 = 1
-int lzx_launch_iso_fill(lzx_ctx *c, u32 k);                          // q_j[i] = c_j q_0[i] for those rows, j = 1 .. k - 1
+int lzx_launch_iso_fill(lzx_ctx *c, u32 k);                          // q_j[i] = c_j q_0[i] for those rows, the columns below k that are not there yet
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr,
-                           float *f32_next = nullptr);
+                           float *f32_next = nullptr, u32 mail_world = 0);   // mail_world > 0: scal2 is a mailbox of that many [D, B] pairs
 int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *pa, u32 na,
                                  const double *pb, u32 nb, int first, double *alpha_out, double *beta_out, double *q_out,
                                  double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr, float *f32_next = nullptr);
@@ -352,4 +361,8 @@ int lzx_launch_to_f32(lzx_ctx *c, const double *in, float *out, u64 count);
 int lzx_launch_to_f64(lzx_ctx *c, const float *in, double *out, u64 count);
 // everything queued so far on every handle's `from` stream happens before what is queued next on every `to` stream
 int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream2);
+// in-process group, lazy loop: every handle's [D, B] into every peer's mailbox (parity = iteration & 1), then one barrier;
+// returns false (nothing queued) when the group cannot use mailboxes (no peer access): the caller takes the all-reduce
+bool lzx_comm_mail_usable(std::vector<lzx_ctx *> &cs);
+int lzx_comm_mail_reduce2(std::vector<lzx_ctx *> &cs, u32 parity, bool first);
 void lzx_comm_release(lzx_ctx *c);

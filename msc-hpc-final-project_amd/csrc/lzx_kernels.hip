@@ -132,11 +132,17 @@ __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict__ u, const double *__restrict__ q_prev,
               const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
               double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n, double *iso, u32 iso_k, u32 iso_j,
-              const double *prev_div, float *f32_next)
+              const double *prev_div, float *f32_next, u32 mail_world)
 {
     __shared__ double sh[4];
     double D, B;
-    if (scal2) {
+    if (scal2 && mail_world) {   // in-process group: the ranks' pairs as their reduce kernels wrote them, added in rank order
+        D = B = 0.0;
+        for (u32 p = 0; p < mail_world; ++p) {
+            D += scal2[2 * p];
+            B += scal2[2 * p + 1];
+        }
+    } else if (scal2) {
         D = scal2[0];
         B = scal2[1];
     } else {
@@ -203,6 +209,21 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = nrm;
     __syncthreads();
     if (threadIdx.x == 0) partials_out[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// the same two sums, stored into slot [rank] of every peer's mailbox (in-process groups; lzx_internal.h: d_mail)
+__global__ void __launch_bounds__(LZX_VEC_BLOCK)
+k_reduce2_mail(const double *pa, u32 na, const double *pb, u32 nb, const MailPeers peers, u32 world)
+{
+    __shared__ double sh[4];
+    const double a = block_sum_fixed_256(pa, na, sh);
+    __syncthreads();
+    const double b = block_sum_fixed_256(pb, nb, sh);
+    if (threadIdx.x < world) {
+        double *o = peers.slot[threadIdx.x];
+        o[0] = a;
+        o[1] = b;
+    }
 }
 
 // two fixed-order sums in one launch: out2[0] = sum pa, out2[1] = sum pb
@@ -346,12 +367,12 @@ k_iso_prepare(const double *partials, u32 np, double *iso, u32 iso_k)
 
 // basis columns 1 .. k-1 of the rows without an edge, materialised: q_j[i] = c_j q_0[i]
 template <typename QT>
-__global__ void k_iso_fill(QT *Q, u32 ldq, u32 k, u32 r0, u32 r1, const double *coeff)
+__global__ void k_iso_fill(QT *Q, u32 ldq, u32 j0, u32 k, u32 r0, u32 r1, const double *coeff)
 {
     const u32 i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r1) return;
     const double z = Q[i];
-    for (u32 j = 1; j < k; ++j) Q[(size_t)j * ldq + i] = (QT)(coeff[j] * z);
+    for (u32 j = j0; j < k; ++j) Q[(size_t)j * ldq + i] = (QT)(coeff[j] * z);
 }
 
 // One step of the Arnoldi pass of serial/lib/lanczos.cc:85-90 (decompose_with_arnoldi), fused the way the dependent
@@ -552,6 +573,13 @@ int lzx_launch_reduce(lzx_ctx *c, const double *partials, u32 np, double *out, i
     return LZX_OK;
 }
 
+int lzx_launch_reduce2_mail(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, const MailPeers &peers, u32 world)
+{
+    hipLaunchKernelGGL(k_reduce2_mail, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, pa, na, pb, nb, peers, world);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
 int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, double *out2)
 {
     hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, pa, na, pb, nb, out2);
@@ -561,12 +589,12 @@ int lzx_launch_reduce2(lzx_ctx *c, const double *pa, u32 na, const double *pb, u
 
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out,
-                           const double *prev_div, float *f32_next)
+                           const double *prev_div, float *f32_next, u32 mail_world)
 {
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
                        first, alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next);
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next, mail_world);
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
@@ -579,7 +607,7 @@ int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const 
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, nullptr, pa, na, pb, nb, first,
                        alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next);
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next, 0u);
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
@@ -694,7 +722,8 @@ int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_la
 int lzx_launch_multout(lzx_ctx *c, const double *t_dev, u32 k, double *out_loc)
 {
     const u32 g = (c->n_loc_pad + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
-    const bool factored = c->iso_on && !c->iso_filled;
+    // rows without an edge: always from the scalars (valid whether or not a fetch has materialised some columns meanwhile)
+    const bool factored = c->iso_on;
     const double *tq = t_dev;
     if ((u64)k * (c->basis_u ? 2u : 1u) > c->np_cap)   // t (and, with the unnormalised basis, k more doubles) live in a partials buffer
         LZX_FAIL(LZX_ERR_LIMIT, "lzx_launch_multout: k = %u does not fit the coefficient staging (%u doubles)", k, c->np_cap);
@@ -731,14 +760,16 @@ int lzx_launch_iso_prepare(lzx_ctx *c, u32 k)
 
 int lzx_launch_iso_fill(lzx_ctx *c, u32 k)
 {
-    if (k > 1 && c->n_loc_pad > c->rows_live) {
+    const u32 j0 = c->iso_cols_filled < 1 ? 1u : c->iso_cols_filled;   // columns below j0 are there already
+    if (k > j0 && c->n_loc_pad > c->rows_live) {
         const u32 rows = c->n_loc_pad - c->rows_live;
         const double *coeff = c->basis_u ? c->d_iso + c->iso_cap + 1 : c->d_iso;   // d_j where the columns hold u_j, c_j otherwise
         if (c->qf32)
-            hipLaunchKernelGGL(k_iso_fill<float>, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Qf, c->ldq, k, c->rows_live, c->n_loc_pad, coeff);
+            hipLaunchKernelGGL(k_iso_fill<float>, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Qf, c->ldq, j0, k, c->rows_live, c->n_loc_pad, coeff);
         else
-        hipLaunchKernelGGL(k_iso_fill<double>, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Q, c->ldq, k, c->rows_live, c->n_loc_pad, coeff);
+        hipLaunchKernelGGL(k_iso_fill<double>, dim3((rows + 255) / 256), dim3(256), 0, c->stream, c->d_Q, c->ldq, j0, k, c->rows_live, c->n_loc_pad, coeff);
         LZX_HIP(hipGetLastError());
     }
+    if (k > c->iso_cols_filled) c->iso_cols_filled = k;
     return LZX_OK;
 }

@@ -149,6 +149,37 @@ def test_c3_full_size_properties(pkg, oracle):
     eng.close()
 
 
+def test_er_full_size(pkg, oracle):
+    """north_star's uniform family at its "100 M-edge graph": Erdos-Renyi G(n, M), n = 10 M, 100 M draws (bench.py --workload
+    er).  No hubs: every (row, column band) pair holds about one entry, so every entry crosses the two passes as a value
+    (DESIGN.md section 3.2).  One SpMV of a random vector against the ORACLE, the size-independent properties, and the
+    generator bit for bit against the oracle's (the same integer specification)."""
+    O = oracle
+    n, draws = 10_000_000, 100_000_000
+    eng = pkg.Engine(0)
+    eng.gen_er(n, draws, 1234)
+    gi = eng.info()
+    assert gi["n"] == n and 199_000_000 < gi["nnz"] <= 2 * draws and gi["max_degree"] < 100
+    rp, ci = eng.get_graph_csr()
+    x = np.random.default_rng(44).random(n)
+    y, y_ref = eng.spmv(x), O.spmv(rp, ci, x)
+    assert np.allclose(y, y_ref, rtol=1e-13, atol=0)
+    deg = np.diff(rp.astype(np.int64))
+    assert (y[deg == 0] == 0).all()
+    del rp, ci, y, y_ref, deg
+    check_properties(eng, n, 5, np.random.default_rng(5))
+    eng.close()
+    # the generator: a smaller instance of the same family against the oracle's keys (10 M draws)
+    eng = pkg.Engine(0)
+    eng.gen_er(1_000_000, 10_000_000, 1234)
+    rp, ci = eng.get_graph_csr()
+    rp_ref, ci_ref = O.gen_er(1_000_000, 10_000_000, 1234)
+    assert np.array_equal(rp, rp_ref) and np.array_equal(ci, ci_ref)
+    x = np.random.default_rng(45).random(1_000_000)
+    assert np.allclose(eng.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+    eng.close()
+
+
 def test_edge_cases(pkg, oracle):
     O = oracle
     # no edges at all: A = 0 -> v = 0, alpha = 0; beta_0 = 0 makes q_1 = 0/0 as in the reference (no guard)

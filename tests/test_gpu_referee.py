@@ -154,15 +154,23 @@ def test_reorthogonalised_variant(pkg, oracle):
         print(f"C2 k=50 reorthogonalise=1 cap={cap}: engine vs referee {got:.2e}; Arnoldi passes {st['vec_ms']:.1f} ms of {st['loop_ms']:.1f} ms")
         assert got <= REL_INF_TOL, (cap, got)
     eng.close()
-    eng = pkg.Engine(0, reorthogonalise=2)
-    eng.gen_rmat(20, n, 20_000_000, 1234)
-    a, b, _, xn, _ = eng.lanczos(x0, k, want_q=False)
-    a_ref, b_ref, Q_ref, xn_ref = O.lanczos_arnoldi(rp, ci, k, x0, every=2)
-    bad_engine = rel_inf(eng.multout(shift_weights(O, a, b, xn, cap=40.0)), R["ans"][1])
-    bad_oracle = rel_inf(shift_weights(O, a_ref, b_ref, xn_ref, cap=40.0) @ Q_ref, R["ans"][1])
-    print(f"C2 k=50 reorthogonalise=2 (the reference's constant): engine vs referee {bad_engine:.2e}, oracle restatement vs referee {bad_oracle:.2e}")
-    assert bad_oracle > 1e-3 and bad_engine > 1e-3      # the reference's own finding, reproduced on both sides
-    eng.close()
+    # The reference's own constant (every 2) and every 3: between two passes orthogonality keeps decaying (three- to tenfold per
+    # pass pair on this graph) and once it is gone the pass removes components T does not record.  How soon depends on the
+    # level the decay STARTS from: the oracle's left-to-right sums put it at 1e-11 and it is garbage by k = 50 already with
+    # every 2; the engine starts at 1e-16 and is still fine at k = 50 with every 2 (2e-15; max |q_0 . q_j| has reached 0.14
+    # by then) but not with every 3 (tools/reorth_probe.py, profiles/r3_reorth_probe.txt).
+    for e, expect_engine_bad in ((2, None), (3, True)):
+        eng = pkg.Engine(0, reorthogonalise=e)
+        eng.gen_rmat(20, n, 20_000_000, 1234)
+        a, b, _, xn, _ = eng.lanczos(x0, k, want_q=False)
+        a_ref, b_ref, Q_ref, xn_ref = O.lanczos_arnoldi(rp, ci, k, x0, every=e)
+        bad_engine = rel_inf(eng.multout(shift_weights(O, a, b, xn, cap=40.0)), R["ans"][1])
+        bad_oracle = rel_inf(shift_weights(O, a_ref, b_ref, xn_ref, cap=40.0) @ Q_ref, R["ans"][1])
+        print(f"C2 k=50 reorthogonalise={e}: engine vs referee {bad_engine:.2e}, oracle restatement vs referee {bad_oracle:.2e}")
+        assert bad_oracle > 1e-3                              # the reference's own finding, reproduced by its restatement
+        if expect_engine_bad:
+            assert bad_engine > 1e-3
+        eng.close()
 
 
 def test_run_in_chunks_and_early_stop(pkg, oracle):
