@@ -139,6 +139,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
     else if (!strcmp(name, "unnormalised_basis")) c->basis_u_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
+    else if (!strcmp(name, "pb_gather_tickets")) c->pb_g3_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
 #endif

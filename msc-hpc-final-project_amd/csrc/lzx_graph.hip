@@ -427,6 +427,25 @@ int lzx_graph_prepare(lzx_ctx *c)
         PREP_HIP(e);
         c->max_degree = md;
         c->n_active = h_cnt;
+        // How many x values to stage is a per-GRAPH choice, not a per-size one (round 3): on a uniform graph the 16 Ki
+        // highest-degree columns hold next to nothing (Erdos-Renyi, 10 M vertices / 200 M entries: 0.25 % of the entries), yet
+        // the staged-columns kernel still sweeps every row for them, and 16 Ki fewer columns are what the blocked passes
+        // would have taken anyway.  Measured (profiles/r3_er_probe.txt, SpMV ms with 16384 / 1024 staged): ER 10 M 1.31 /
+        // 1.05, ER 4 M 0.474 / 0.437, ER 1 M (2.5 % of the entries staged) 0.102 / 0.109; R-MAT (31 %) needs them all.
+        // Rule: below 1 % of the entries in the staged columns, stage 1 Ki.  Every rank holds the whole graph and computes
+        // the same share, so all ranks agree without talking.
+        if (pb && c->hub_opt < 0 && c->nnz > 0) {
+            const u32 top = (u32)std::min<u64>(c->hub_real, n);
+            std::vector<u32> hd(top);
+            PREP_HIP(hipMemcpy(hd.data(), d_sdeg, sizeof(u32) * top, hipMemcpyDeviceToHost));
+            u64 staged = 0;
+            for (u32 dgr : hd) staged += dgr;
+            if (staged * 100 < c->nnz && n > 2048) {
+                c->hub_real = 1024;
+                c->hub = c->hub_real + 2;
+                c->spmv_lds = ((size_t)c->hub + LZX_SPMV_BLOCK / 64) * sizeof(double);
+            }
+        }
         const u64 live = h_cnt > rank ? (h_cnt - rank + world - 1) / world : 0;
         c->rows_live = std::min<u32>(c->n_loc_pad, round_up((u32)live, LZX_SLICE));
     }

@@ -222,6 +222,14 @@ struct lzx_ctx {
     int64_t pb_persist_opt = -1;       // persistent passes: -1/1 on, 0 = one workgroup per unit / static item lists
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;
+    // gather pass drawn from a ticket counter (k_pb_gather3, the product form)
+    bool pb_g3 = false;
+    u32 pb_g3_items = 0;
+    uint4 *d_pb_grec = nullptr;        // [pb_g3_items][8][2] fat records, longest item first, one per (item, wavefront)
+    double *d_pb_item_dot = nullptr;   // [pb_g3_items] alpha partial of every item (closed in item order by k_pb_finish)
+    u32 *d_pb_gqueue = nullptr;        // the ticket counter (never reset)
+    u32 pb_gq_base = 0;                // its value when the next launch starts
+    int64_t pb_g3_opt = -1;            // debug knob pb_gather_tickets: 0 = the static longest-first lists (k_pb_gather)
     u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)
     u64 pbr_entries = 0;               // entries of the reduced runs
     uint4 *d_pbr_code = nullptr;       // [pbr_steps][64] scatter order: 8 x (column in band | piece-end flag) per lane

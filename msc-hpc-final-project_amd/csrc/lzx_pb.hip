@@ -783,17 +783,313 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     }
 }
 
+// ---- gather pass, product form (round 3) ------------------------------------------------------------------------
+// What the section stamps of the static form showed on the 10 M-vertex graph (profiles/r3_gather_stamps.txt): while a
+// workgroup streams it runs at the rate of the isolated loop (11 GB/s per workgroup = 5.6 TB/s chip-wide), but only 70 % of
+// its time is streaming -- 14 us per workgroup go to dependent record loads (item -> band tables) before the first value
+// is requested, 16 us to the fold (a dependent read-modify-write of v behind 8 * rep serial LDS reads per row, on a
+// handful of threads for the top bands, whose rows have up to 64 replicas), 7 us to the barrier in between -- and the
+// longest-first static schedule ends 20 % later than its median workgroup (189 vs 152 us).  So:
+//   * items are drawn from a ticket counter in longest-first order (dynamic longest-processing-time: the tail is one small
+//     item long), the next ticket and the next item's record both in flight while the current item streams;
+//   * one fat record per (item, wavefront) holds everything the pass needs -- no dependent table look-ups;
+//   * the fold's v / q operands are requested before the streaming starts; bands with replicas are folded by all 512
+//     threads (row x share of the (tile, replica) pairs, partial sums through LDS, closed in fixed order);
+//   * alpha partials are per ITEM (item_dot[item], closed by k_pb_finish in item order), so which workgroup happened to
+//     draw an item changes no bit of any result.
+// The counter is never reset: a launch advances it by exactly n_items + gridDim.x (every workgroup draws one ticket past
+// the end and none after it), which the host adds to the base it passes to the next launch.
+enum : u32 { LZX_G3_NORMAL = 0, LZX_G3_ONE_ROW = 1, LZX_G3_GROUP = 2, LZX_G3_IDLE = 3 };
+
+template <bool STAMP>
+__global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
+k_pb_gather3(const uint4 *recs /*[n_items][8][2]: beg, end, row0, rows | rep, part slot or ~0, kind, -*/, u32 n_items, u32 *queue,
+             u32 qbase, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
+             double *item_dot, unsigned long long *stamps)
+{
+    unsigned long long t_start = 0, t_mark = 0, t_zero = 0, t_stream = 0, t_bar = 0, t_fold = 0, n_vals = 0;
+    u32 n_it = 0;
+#define GSTAMP(acc) do { if (STAMP) { const unsigned long long t_ = wall_clock64(); acc += t_ - t_mark; t_mark = t_; } } while (0)
+    if (STAMP) t_start = t_mark = wall_clock64();
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
+    constexpr u32 TILE = LZX_PB_RB + 8;                  // + spare slot for padding entries
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    double *ytile = lds + (size_t)wv * TILE;             // private to this wavefront
+    double *wsum = lds + (size_t)WAVES * TILE;           // [WAVES] the item's alpha partial, by wavefront
+    double *fscr = wsum + WAVES;                         // [LZX_PB_GATHER_BLOCK] fold scratch (+ the one-row sum)
+    u32 *tick = reinterpret_cast<u32 *>(fscr + LZX_PB_GATHER_BLOCK);   // [2]
+
+    if (tid == 0) {
+        const u32 t0 = atomicAdd(queue, 1u) - qbase;
+        tick[0] = t0;
+        tick[1] = t0 < n_items ? atomicAdd(queue, 1u) - qbase : 0xffffffffu;
+    }
+    __syncthreads();
+    u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
+    u32 nxt = (u32)__builtin_amdgcn_readfirstlane((int)tick[1]);
+    __syncthreads();
+    if (cur < n_items) {
+        uint4 ra = recs[((size_t)cur * WAVES + wv) * 2], rb = recs[((size_t)cur * WAVES + wv) * 2 + 1];
+        for (;;) {
+            const bool have_next = nxt < n_items;
+            u32 t2 = 0xffffffffu;
+            if (tid == 0 && have_next) t2 = atomicAdd(queue, 1u) - qbase;   // arrives while this item streams
+            uint4 na = ra, nb = rb;
+            if (have_next) {                                                 // so does the next item's record
+                na = recs[((size_t)nxt * WAVES + wv) * 2];
+                nb = recs[((size_t)nxt * WAVES + wv) * 2 + 1];
+            }
+            const u32 beg = ra.x, end = ra.y, row0 = ra.z, rows = ra.w, rep = rb.x, pslot = rb.y, kind = rb.z;
+            double dot = 0.0;
+            if (kind == LZX_G3_GROUP) {
+                // a small band, this wavefront's own (up to eight consecutive ones per item): streamed into its tile and
+                // folded by the wavefront itself -- no workgroup barrier inside
+                const u32 slots = rows * rep;
+                for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
+                __builtin_amdgcn_wave_barrier();
+                if (STAMP) { ++n_it; n_vals += end - beg; }
+                GSTAMP(t_zero);
+                const u32 blocks = (end - beg) / 128u;
+                u32 kb = 0;
+                for (; kb + 8 <= blocks; kb += 8) {
+                    double2 av[8];
+                    u32 sv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const u32 p = beg + (kb + u) * 128u + lane * 2;
+                        av[u] = *reinterpret_cast<const double2 *>(val + p);
+                        sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                        atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                    }
+                }
+                {   // up to seven more blocks and the band's tail (< 128 values): all fetched before the first add
+                    double2 av[7];
+                    u32 sv[7];
+                    double tv[2] = {0.0, 0.0};
+                    u32 ts[2] = {LZX_PB_RB, LZX_PB_RB};
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        if (kb + u < blocks) {           // wave-uniform
+                            const u32 p = beg + (kb + u) * 128u + lane * 2;
+                            av[u] = *reinterpret_cast<const double2 *>(val + p);
+                            sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const u32 i = beg + blocks * 128u + lane + u * 64;
+                        if (i < end) {
+                            tv[u] = val[i];
+                            ts[u] = lslot[i];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        if (kb + u < blocks) {
+                            atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                            atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                        }
+                    }
+                    atomicAdd(&ytile[ts[0]], tv[0]);
+                    __builtin_amdgcn_wave_barrier();   // the tail goes 64 consecutive values per instruction, in order
+                    atomicAdd(&ytile[ts[1]], tv[1]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                GSTAMP(t_stream);
+                // fold: replicas in order; four rows per lane at a time, loads before stores
+                for (u32 j0 = lane; j0 < rows; j0 += 256) {
+                    double vv[4], qq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 j = j0 + u * 64;
+                        vv[u] = j < rows ? v[row0 + j] : 0.0;
+                        qq[u] = j < rows ? q_loc[row0 + j] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 j = j0 + u * 64;
+                        if (j < rows) {
+                            double y = 0.0;
+                            for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                            v[row0 + j] = vv[u] + y;
+                            dot += y * qq[u];
+                        }
+                    }
+                }
+                GSTAMP(t_fold);
+            } else if (kind == LZX_G3_ONE_ROW) {
+                // one heavy row: plain strided sum (padding holds zeros), fixed reduction order
+                if (STAMP) { ++n_it; n_vals += end - beg; }
+                double acc = 0.0;
+                u32 i = beg + tid;
+                for (; i + 7 * LZX_PB_GATHER_BLOCK < end; i += 8 * LZX_PB_GATHER_BLOCK) {
+                    double a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = val[i + u * LZX_PB_GATHER_BLOCK];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += a[u];
+                }
+                for (; i < end; i += LZX_PB_GATHER_BLOCK) acc += val[i];
+                acc = wave_sum_pb(acc);
+                if (lane == 0) fscr[wv] = acc;
+                GSTAMP(t_stream);
+                __syncthreads();
+                if (tid == 0) {
+                    double t = 0.0;
+                    for (u32 w = 0; w < WAVES; ++w) t += fscr[w];
+                    if (pslot == 0xffffffffu) {
+                        v[row0] += t;
+                        dot = t * q_loc[row0];
+                    } else {
+                        part[pslot] = t;
+                    }
+                }
+                GSTAMP(t_fold);
+            } else if (kind == LZX_G3_NORMAL) {
+                if (STAMP) { ++n_it; n_vals += end - beg; }
+                const bool into_v = pslot == 0xffffffffu;
+                // the fold's operands, requested now (rep == 1: a thread folds rows tid and tid + 512)
+                double vv[2] = {0.0, 0.0}, qq[2] = {0.0, 0.0};
+                if (into_v && rep == 1) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
+                        const u32 jc = j < rows ? j : 0;            // clamped: unconditional loads
+                        vv[u] = v[row0 + jc];
+                        qq[u] = q_loc[row0 + jc];
+                    }
+                }
+                const u32 slots = rows * rep;
+                for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
+                __builtin_amdgcn_wave_barrier();
+                GSTAMP(t_zero);
+                // whole blocks of 128 values (an item begins on a block boundary of its band): lane l owns values 2 l, 2 l + 1
+                // of its wavefront's blocks; eight blocks in flight per wavefront
+                const u32 blocks = (end - beg) / 128u;
+                u32 kb = wv;
+                for (; kb + 7 * WAVES < blocks; kb += 8 * WAVES) {
+                    double2 av[8];
+                    u32 sv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const u32 p = beg + (kb + u * WAVES) * 128u + lane * 2;
+                        av[u] = *reinterpret_cast<const double2 *>(val + p);
+                        sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                        atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                    }
+                }
+                for (; kb < blocks; kb += WAVES) {
+                    const u32 p = beg + kb * 128u + lane * 2;
+                    const double2 a = *reinterpret_cast<const double2 *>(val + p);
+                    const u32 sl = *reinterpret_cast<const u32 *>(lslot + p);
+                    atomicAdd(&ytile[sl & 0xffffu], a.x);
+                    atomicAdd(&ytile[sl >> 16], a.y);
+                }
+                // the band's tail (< 128 values): 64 consecutive values per instruction, wavefront 0
+                if (wv == 0)
+                    for (u32 i = beg + blocks * 128u + lane; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
+                GSTAMP(t_stream);
+                __syncthreads();
+                GSTAMP(t_bar);
+                if (rep == 1) {
+                    // a thread per row: the eight wavefront tiles in order
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
+                        if (j < rows) {
+                            double y = 0.0;
+#pragma unroll
+                            for (u32 w = 0; w < WAVES; ++w) y += lds[(size_t)w * TILE + j];
+                            if (into_v) {
+                                v[row0 + j] = vv[u] + y;
+                                dot += y * qq[u];
+                            } else {
+                                part[pslot + j] = y;
+                            }
+                        }
+                    }
+                } else {
+                    // rows with replicas (rows * rep <= 1024, so rows <= 512): all threads share the 8 * rep (tile, replica)
+                    // pairs of every row -- thread = (row, share); shares closed per row in share order
+                    u32 rows_p = 1;
+                    while (rows_p < rows) rows_p <<= 1;
+                    const u32 shares = LZX_PB_GATHER_BLOCK / rows_p;
+                    const u32 row = tid & (rows_p - 1u), share = tid / rows_p;
+                    if (row < rows) {
+                        double sacc = 0.0;
+                        u32 w = share / rep, t = share % rep;
+                        while (w < WAVES) {
+                            sacc += lds[(size_t)w * TILE + row * rep + t];
+                            t += shares;
+                            while (t >= rep) { t -= rep; ++w; }
+                        }
+                        fscr[share * rows_p + row] = sacc;
+                    }
+                    __syncthreads();
+                    if (tid < rows) {
+                        double y = 0.0;
+                        for (u32 sh = 0; sh < shares; ++sh) y += fscr[sh * rows_p + tid];
+                        if (into_v) {
+                            const double qv = q_loc[row0 + tid];
+                            v[row0 + tid] += y;
+                            dot += y * qv;
+                        } else {
+                            part[pslot + tid] = y;
+                        }
+                    }
+                }
+                GSTAMP(t_fold);
+            }
+            // the item's alpha partial: wavefronts in order; the next ticket travels with the same barrier
+            dot = wave_sum_pb(dot);
+            if (lane == 0) wsum[wv] = dot;
+            if (tid == 0) tick[0] = t2;
+            __syncthreads();
+            if (tid == 0) {
+                double sdot = 0.0;
+                for (u32 w = 0; w < WAVES; ++w) sdot += wsum[w];
+                item_dot[cur] = sdot;
+            }
+            const u32 t2_all = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
+            __syncthreads();                  // tiles, wsum, fscr and tick are free again
+            if (!have_next) break;
+            cur = nxt;
+            nxt = t2_all;
+            ra = na;
+            rb = nb;
+        }
+    }
+    if (STAMP && tid == 0) {
+        unsigned long long *o = stamps + 8 * (size_t)blockIdx.x;
+        o[0] = t_start; o[1] = wall_clock64(); o[2] = t_zero; o[3] = t_stream; o[4] = t_bar; o[5] = t_fold; o[6] = n_it; o[7] = n_vals;
+    }
+#undef GSTAMP
+}
+
 // v[row] += totals that were left for it, in their fixed order; alpha partials for those rows.  Threads [0, n_multi):
 // rows of bands cut into several gather items (their per-item totals); threads behind them: the split rows of the
 // staged-column kernel (their item totals, k_long_finish's job in plain mode).
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32 n_multi, const double *part,
             const u32 *item_first, const double *long_partial, const uint8_t *long_is_multi, u32 n_long, double *v,
-            const double *q_loc, double *partials)
+            const double *q_loc, double *partials, const double *item_dot, u32 n_item_dot)
 {
     __shared__ double sh[4];
     const u32 t = blockIdx.x * LZX_VEC_BLOCK + threadIdx.x;
     double dot = 0.0;
+    // the gather pass's per-item alpha partials (k_pb_gather3), 256 per block in item order: nothing depends on which
+    // workgroup drew which item
+    const double idot = t < n_item_dot ? item_dot[t] : 0.0;
     if (t < n_multi) {
         const uint4 m = multi[t];
         const u32 row = m.x;
@@ -810,6 +1106,7 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
         v[r] += s;
         dot = s * q_loc[r];
     }
+    dot += idot;
     dot = wave_sum_pb(dot);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
     __syncthreads();
@@ -1349,6 +1646,11 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_seg_begin);
     pb_free(c->d_pb_stamps);
     pb_free(c->d_pb_gstamps);
+    pb_free(c->d_pb_grec);
+    pb_free(c->d_pb_item_dot);
+    pb_free(c->d_pb_gqueue);
+    c->pb_g3 = false;
+    c->pb_gq_base = 0;
     pb_free(c->d_pb_queue);
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
@@ -1361,7 +1663,8 @@ void lzx_pb_release(lzx_ctx *c)
     c->pbr_steps = 0;
 }
 
-u32 lzx_pb_partials(const lzx_ctx *c) { return c->pb ? c->pb_gather_grid + c->pb_finish_grid : 0; }
+// block partials of alpha the blocked passes leave: the ticketed gather pass hands its per-item partials to k_pb_finish
+u32 lzx_pb_partials(const lzx_ctx *c) { return c->pb ? (c->pb_g3 ? 0u : c->pb_gather_grid) + c->pb_finish_grid : 0; }
 
 namespace {
 // ---- build helpers: every one leaves its temporaries to the caller's arena, which frees them on any exit ----------
@@ -1921,6 +2224,15 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(pb_alloc(&c->d_pb_beg, (u64)nr + 1));
     LZX_HIP(hipMemcpyAsync(c->d_pb_beg, rstart.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
     const u32 group_cap = c->pb_group_opt >= 0 ? (u32)c->pb_group_opt : LZX_PB_GROUP;
+    // product form of the gather pass: tickets over fat records (k_pb_gather3); the static longest-first lists
+    // (k_pb_gather) remain in the debug library behind the knob pb_gather_tickets = 0
+    bool g3 = c->pb_gather_block == 512u && c->pb_persist_opt <= 0;
+#ifdef LZX_DEBUG_KNOBS
+    if (c->pb_g3_opt == 0) g3 = false;
+#endif
+    c->pb_g3 = g3;
+    std::vector<u32> g3_out;      // items after grouping {R | first band, begin | bands, end | values, slot | marker}
+    std::vector<u64> g3_cost;
     if (group_cap > 0 && c->pb_gather_block == 512u && c->pb_persist_opt <= 0) {
         // Small bands (the low-degree end of the row order: thousands of bands of a few thousand values, each of which
         // cost a workgroup three dependent round trips and two barriers) are gathered by ONE wavefront each, up to eight
@@ -1961,6 +2273,10 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             // a group lasts as long as its widest band's wavefront: eight serial batches per Ki values
             cost.push_back(std::max<u64>(10ull * vals + 24ull * rows, 80ull * widest) + 40000ull);
             i = j;
+        }
+        if (g3) {
+            g3_out = out;
+            g3_cost = cost;
         }
         const u32 G = c->pb_gather_grid;
         const size_t no = cost.size();
@@ -2039,6 +2355,51 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         LZX_HIP(hipStreamSynchronize(st));
     }
 #endif
+    if (g3) {
+        // fat records, longest item first: {beg, end, row0, rows | rep, part slot or ~0, kind, bands} per (item, wavefront)
+        if (g3_out.empty()) {     // no grouping: the items as they were made (items[] is still in that form)
+            for (size_t i = 0; i + 3 < items.size(); i += 4) {
+                if (items[i + 3] == LZX_PB_ITEM_NONE || items[i + 3] == LZX_PB_ITEM_GROUP) continue;
+                const u32 R = items[i];
+                g3_out.insert(g3_out.end(), items.begin() + i, items.begin() + i + 4);
+                g3_cost.push_back(10ull * (items[i + 2] - items[i + 1]) + 24ull * (row0[R + 1] - row0[R]) + 40000ull);
+            }
+        }
+        const size_t no = g3_cost.size();
+        std::vector<u32> order(no);
+        for (size_t i = 0; i < no; ++i) order[i] = (u32)i;
+        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b2) { return g3_cost[a] > g3_cost[b2]; });
+        std::vector<u32> recs(no * 8 * 8, 0u);
+        for (size_t k = 0; k < no; ++k) {
+            const u32 *it = &g3_out[4 * (size_t)order[k]];
+            for (u32 w = 0; w < 8; ++w) {
+                u32 *o = &recs[(k * 8 + w) * 8];
+                if (it[3] == LZX_PB_ITEM_GROUP) {
+                    if (w < it[1]) {
+                        const u32 R = it[0] + w;
+                        o[0] = rstart[R]; o[1] = rstart[R + 1]; o[2] = row0[R]; o[3] = row0[R + 1] - row0[R];
+                        o[4] = rep[R]; o[5] = 0xffffffffu; o[6] = LZX_G3_GROUP; o[7] = it[1];
+                    } else {
+                        o[6] = LZX_G3_IDLE;
+                    }
+                } else {
+                    const u32 R = it[0], rows = row0[R + 1] - row0[R];
+                    o[0] = it[1]; o[1] = it[2]; o[2] = row0[R]; o[3] = rows;
+                    o[4] = rep[R]; o[5] = it[3]; o[6] = rows == 1 ? LZX_G3_ONE_ROW : LZX_G3_NORMAL; o[7] = 1;
+                }
+            }
+        }
+        c->pb_g3_items = (u32)no;
+        c->pb_gather_grid = std::min<u32>((u32)c->cu_count * 2u, std::max<u32>(1u, (u32)no));
+        LZX_TRY(pb_alloc(reinterpret_cast<u32 **>(&c->d_pb_grec), recs.size()));
+        if (!recs.empty()) LZX_HIP(hipMemcpyAsync(c->d_pb_grec, recs.data(), sizeof(u32) * recs.size(), hipMemcpyHostToDevice, st));
+        LZX_TRY(pb_alloc(&c->d_pb_item_dot, (u64)no));
+        LZX_HIP(hipMemsetAsync(c->d_pb_item_dot, 0, sizeof(double) * std::max<size_t>(no, 1), st));
+        LZX_TRY(pb_alloc(&c->d_pb_gqueue, 4));
+        LZX_HIP(hipMemsetAsync(c->d_pb_gqueue, 0, sizeof(u32) * 4, st));
+        c->pb_gq_base = 0;
+        LZX_HIP(hipStreamSynchronize(st));
+    }
 #ifdef LZX_DEBUG_KNOBS
     if (c->pb_stamps_opt > 0 && c->pb_persist_opt <= 0) {   // per-workgroup section stamps of the product gather pass
         LZX_TRY(pb_alloc(&c->d_pb_gstamps, 8 * (u64)c->pb_gather_grid));
@@ -2072,6 +2433,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     (void)waves_per_wg;
     c->pb_finish_grid = (c->pb_n_multi + c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;   // + the split rows of k_spmv
+    if (c->pb_g3) c->pb_finish_grid = std::max<u32>(c->pb_finish_grid, (c->pb_g3_items + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK);   // + the gather pass's item partials
     return LZX_OK;
 }
 #undef GRID
@@ -2188,6 +2550,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     }
     if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double);
+    const size_t lds3 = lds2 + ((size_t)LZX_PB_GATHER_BLOCK + 2) * sizeof(double);   // + fold scratch and the two ticket words
     LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     if (c->phase_mask_opt & 8) {
@@ -2201,12 +2564,24 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         hipLaunchKernelGGL(gk, dim3(c->pb_gather_grid), dim3(block), lds2p, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_items2), c->d_pb_wg_begin, c->d_pb_lrow, c->d_pb_val, v, q_loc,
                            c->d_pb_part, partials, c->d_pb_stamps ? c->d_pb_stamps + 8192 : nullptr);
+    } else if (c->pb_g3 && c->pb_stamps_opt > 0 && c->d_pb_gstamps) {
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        hipLaunchKernelGGL(k_pb_gather3<true>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds3, c->stream,
+                           reinterpret_cast<const uint4 *>(c->d_pb_grec), c->pb_g3_items, c->d_pb_gqueue, c->pb_gq_base, c->d_pb_lrow,
+                           c->d_pb_val, v, q_loc, c->d_pb_part, c->d_pb_item_dot, c->d_pb_gstamps);
+        c->pb_gq_base += c->pb_g3_items + c->pb_gather_grid;
     } else if (c->pb_stamps_opt > 0 && c->d_pb_gstamps) {
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_pb_gather<true>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,
                            c->d_pb_val, v, q_loc, c->d_pb_part, partials, c->d_pb_gstamps);
 #endif
+    } else if (c->pb_g3) {
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        hipLaunchKernelGGL(k_pb_gather3<false>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds3, c->stream,
+                           reinterpret_cast<const uint4 *>(c->d_pb_grec), c->pb_g3_items, c->d_pb_gqueue, c->pb_gq_base, c->d_pb_lrow,
+                           c->d_pb_val, v, q_loc, c->d_pb_part, c->d_pb_item_dot, nullptr);
+        c->pb_gq_base += c->pb_g3_items + c->pb_gather_grid;   // what the launch advances the ticket counter by
     } else
     hipLaunchKernelGGL(k_pb_gather<false>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,
@@ -2214,7 +2589,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     if (c->pb_finish_grid)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, c->d_item_first,
-                           c->d_long_partial, c->d_pb_long_multi, c->n_long64, v, q_loc, partials + c->pb_gather_grid);
+                           c->d_long_partial, c->d_pb_long_multi, c->n_long64, v, q_loc, partials + (c->pb_g3 ? 0u : c->pb_gather_grid),
+                           c->pb_g3 ? c->d_pb_item_dot : nullptr, c->pb_g3 ? c->pb_g3_items : 0u);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }
