@@ -241,7 +241,8 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           vectors the recurrence works on stay fp64, so alpha / beta are those of the fp64 loop bit for
  *                           bit; lzx_multout_f64 and the host fetch read the rounded columns (6e-8 relative per entry:
  *                           the centrality vector ends near 1e-8, outside the 1e-10 criterion; the reference's float runs
- *                           end at 1.2e-6, parallel-final/output/single_double.txt:58-63).  Lazy loop only.  Default 0.
+ *                           end at 1.2e-6, parallel-final/output/single_double.txt:58-63).  Selects the lazy loop (an error with
+ *                           lazy_normalisation = 0 or reorthogonalise).  Default 0.
  *                           SURVEY 8(f) N4.  May be changed between decompositions.
  * These nine are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
  * "phase_mask", "exchange_at_world_1", ...) exist only in liblzx_dbg.so, the same sources built with -DLZX_DEBUG_KNOBS

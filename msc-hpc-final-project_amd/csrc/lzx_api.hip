@@ -254,6 +254,7 @@ static int ensure_capacity(lzx_ctx *c, u32 k)
 static bool loop_is_lazy(const lzx_ctx *c0)
 {
     if (c0->reorth_opt > 0) return false;   // R1 runs the reference's operation order on the normalised basis
+    if (c0->qf32_opt > 0 && c0->lazy_opt != 0) return true;   // the fp32-stored basis lives in the lazy loop: asking for it selects it
     return c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (lzx_exchanges(c0) || c0->codes16));
 }
 // fp64 column j of the basis: a column of d_Q, or -- basis stored as fp32 -- one of the three live vectors
@@ -310,7 +311,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     for (lzx_ctx *c : cs) {
         if (c->reorth_opt != c0->reorth_opt || c->qf32_opt != c0->qf32_opt) LZX_FAIL(LZX_ERR_STATE, "handles carry different loop options");
         if (c->qf32_opt > 0 && (!lazy || c->basis_u_opt == 0))
-            LZX_FAIL(LZX_ERR_STATE, "basis_fp32 needs the lazy loop (option lazy_normalisation = 1; not together with reorthogonalise)");
+            LZX_FAIL(LZX_ERR_STATE, "basis_fp32 needs the lazy loop (not with lazy_normalisation = 0, not together with reorthogonalise)");
         c->qf32 = c->qf32_opt > 0;
         c->k_prep = 0;
     }

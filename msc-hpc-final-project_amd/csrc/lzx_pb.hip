@@ -803,7 +803,7 @@ enum : u32 { LZX_G3_NORMAL = 0, LZX_G3_ONE_ROW = 1, LZX_G3_GROUP = 2, LZX_G3_IDL
 
 template <bool STAMP>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
-k_pb_gather3(const uint4 *recs /*[n_items][8][2]: beg, end, row0, rows | rep, part slot or ~0, kind, -*/, u32 n_items, u32 *queue,
+k_pb_gather3(const uint4 *__restrict__ recs /*[n_items][8][2]: beg, end, row0, rows | rep, part slot or ~0, kind, -*/, u32 n_items, u32 *queue,
              u32 qbase, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
              double *item_dot, unsigned long long *stamps)
 {
@@ -831,17 +831,34 @@ k_pb_gather3(const uint4 *recs /*[n_items][8][2]: beg, end, row0, rows | rep, pa
     u32 nxt = (u32)__builtin_amdgcn_readfirstlane((int)tick[1]);
     __syncthreads();
     if (cur < n_items) {
+        // (records come through the scalar cache -- the array is read-only and the address wave-uniform; the compiler waits
+        //  for a scalar load where it issues it, so the next record costs one scalar round trip per item instead of the static
+        //  form's two dependent vector ones; attempts to keep it in flight in VGPRs ended in waits the register allocator
+        //  introduced by re-using the destination registers)
         uint4 ra = recs[((size_t)cur * WAVES + wv) * 2], rb = recs[((size_t)cur * WAVES + wv) * 2 + 1];
         for (;;) {
             const bool have_next = nxt < n_items;
-            u32 t2 = 0xffffffffu;
-            if (tid == 0 && have_next) t2 = atomicAdd(queue, 1u) - qbase;   // arrives while this item streams
-            uint4 na = ra, nb = rb;
-            if (have_next) {                                                 // so does the next item's record
-                na = recs[((size_t)nxt * WAVES + wv) * 2];
-                nb = recs[((size_t)nxt * WAVES + wv) * 2 + 1];
-            }
+            // The next ticket and the next item's record travel while this item streams.  Both are issued UNCONDITIONALLY:
+            // a load or a returning atomic under an `if` is waited for at the end of that `if` (the compiler cannot carry
+            // an unknown number of outstanding operations across the join: the ISA showed s_waitcnt vmcnt(0) right behind
+            // the atomic and the record loads, two exposed round trips per item).  So every lane of wavefront 0 adds --
+            // lane 0 one to the counter (zero when no ticket is wanted), the others zero to words of their own in a dummy
+            // line -- and the record is loaded from a clamped index.
+            const u32 nx = have_next ? nxt : cur;
+            const uint4 na = recs[((size_t)nx * WAVES + wv) * 2], nb = recs[((size_t)nx * WAVES + wv) * 2 + 1];
             const u32 beg = ra.x, end = ra.y, row0 = ra.z, rows = ra.w, rep = rb.x, pslot = rb.y, kind = rb.z;
+            u32 t2 = 0xffffffffu;
+            if (wv == 0) t2 = atomicAdd(lane == 0 ? queue : queue + 64 + lane, (lane == 0 && have_next) ? 1u : 0u);   // (- qbase where it is used)
+            // the fold's operands of a one-item band, requested now (rep == 1: a thread folds rows tid and tid + 512); loaded
+            // whether or not they will be used (clamped to the band's first row), for the same reason
+            double vv[2], qq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
+                const u32 jc = j < rows ? j : 0;
+                vv[u] = v[row0 + jc];
+                qq[u] = q_loc[row0 + jc];
+            }
             double dot = 0.0;
             if (kind == LZX_G3_GROUP) {
                 // a small band, this wavefront's own (up to eight consecutive ones per item): streamed into its tile and
@@ -954,17 +971,6 @@ k_pb_gather3(const uint4 *recs /*[n_items][8][2]: beg, end, row0, rows | rep, pa
             } else if (kind == LZX_G3_NORMAL) {
                 if (STAMP) { ++n_it; n_vals += end - beg; }
                 const bool into_v = pslot == 0xffffffffu;
-                // the fold's operands, requested now (rep == 1: a thread folds rows tid and tid + 512)
-                double vv[2] = {0.0, 0.0}, qq[2] = {0.0, 0.0};
-                if (into_v && rep == 1) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const u32 j = tid + u * LZX_PB_GATHER_BLOCK;
-                        const u32 jc = j < rows ? j : 0;            // clamped: unconditional loads
-                        vv[u] = v[row0 + jc];
-                        qq[u] = q_loc[row0 + jc];
-                    }
-                }
                 const u32 slots = rows * rep;
                 for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
                 __builtin_amdgcn_wave_barrier();
@@ -1053,15 +1059,14 @@ k_pb_gather3(const uint4 *recs /*[n_items][8][2]: beg, end, row0, rows | rep, pa
             // the item's alpha partial: wavefronts in order; the next ticket travels with the same barrier
             dot = wave_sum_pb(dot);
             if (lane == 0) wsum[wv] = dot;
-            if (tid == 0) tick[0] = t2;
+            if (tid == 0) tick[0] = have_next ? t2 - qbase : 0xffffffffu;
             __syncthreads();
-            if (tid == 0) {
-                double sdot = 0.0;
+            double sdot = 0.0;
+            if (tid == 0)
                 for (u32 w = 0; w < WAVES; ++w) sdot += wsum[w];
-                item_dot[cur] = sdot;
-            }
             const u32 t2_all = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
             __syncthreads();                  // tiles, wsum, fscr and tick are free again
+            if (tid == 0) item_dot[cur] = sdot;   // (behind the barrier: a barrier waits for the stores before it)
             if (!have_next) break;
             cur = nxt;
             nxt = t2_all;
@@ -2395,8 +2400,8 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         if (!recs.empty()) LZX_HIP(hipMemcpyAsync(c->d_pb_grec, recs.data(), sizeof(u32) * recs.size(), hipMemcpyHostToDevice, st));
         LZX_TRY(pb_alloc(&c->d_pb_item_dot, (u64)no));
         LZX_HIP(hipMemsetAsync(c->d_pb_item_dot, 0, sizeof(double) * std::max<size_t>(no, 1), st));
-        LZX_TRY(pb_alloc(&c->d_pb_gqueue, 4));
-        LZX_HIP(hipMemsetAsync(c->d_pb_gqueue, 0, sizeof(u32) * 4, st));
+        LZX_TRY(pb_alloc(&c->d_pb_gqueue, 128));   // word 0: the ticket counter; words 64 ..: the dummy line (see k_pb_gather3)
+        LZX_HIP(hipMemsetAsync(c->d_pb_gqueue, 0, sizeof(u32) * 128, st));
         c->pb_gq_base = 0;
         LZX_HIP(hipStreamSynchronize(st));
     }
