@@ -460,7 +460,20 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int u = 0; u < 4; ++u) body(c[u], b[u]);
         }
-        for (; s < end; s += W) body(scode[(size_t)s * 64 + lane], (u32)__builtin_amdgcn_readfirstlane((int)sbase[s]));
+        {   // up to three more steps: requested together (wave-uniform predicates), not one round trip each
+            uint4 c[3];
+            u32 b[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (s + u * W < end) {
+                    c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                    b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (s + u * W < end) body(c[u], b[u]);
+        }
     }
 
     {   // ---- plain bands
@@ -495,16 +508,28 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                 if (ablate != 3) out[1] = hi;
             }
         }
-        for (; j < wend; j += 64) {
-            const uint2 c = q_lcol[j];
-            double2 lo, hi;
-            lo.x = tile[c.x & 0xffffu];
-            lo.y = tile[c.x >> 16];
-            hi.x = tile[c.y & 0xffffu];
-            hi.y = tile[c.y >> 16];
-            double2 *out = reinterpret_cast<double2 *>(val + q_dst[j]);
-            out[0] = lo;
-            out[1] = hi;
+        {   // up to three more quads per lane (the last one partly filled): requested together
+            uint2 c[3];
+            u32 d[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const u32 jj = j + u * 64 < wend ? j + u * 64 : blk;     // clamped: unconditional loads
+                c[u] = q_lcol[jj];
+                d[u] = q_dst[jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (j + u * 64 < wend) {
+                    double2 lo, hi;
+                    lo.x = tile[c[u].x & 0xffffu];
+                    lo.y = tile[c[u].x >> 16];
+                    hi.x = tile[c[u].y & 0xffffu];
+                    hi.y = tile[c[u].y >> 16];
+                    double2 *out = reinterpret_cast<double2 *>(val + d[u]);
+                    out[0] = lo;
+                    out[1] = hi;
+                }
+            }
         }
         }
     }
@@ -797,12 +822,14 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
 //     threads (row x share of the (tile, replica) pairs, partial sums through LDS, closed in fixed order);
 //   * alpha partials are per ITEM (item_dot[item], closed by k_pb_finish in item order), so which workgroup happened to
 //     draw an item changes no bit of any result.
-// The counter is never reset: a launch advances it by exactly n_items + gridDim.x (every workgroup draws one ticket past
-// the end and none after it), which the host adds to the base it passes to the next launch.
+// The counter is never reset: items 0 .. 2 G - 1 (G = grid size <= n_items) are dealt statically, the counter hands out the
+// rest, and a workgroup draws while its next item exists and stops at its first ticket past the end -- n_items - 2 G draws
+// that find an item plus one per workgroup (n_items >= 2 G), or one per workgroup whose second static item exists: n_items
+// - G draws either way, which the host adds to the base it passes to the next launch.
 enum : u32 { LZX_G3_NORMAL = 0, LZX_G3_ONE_ROW = 1, LZX_G3_GROUP = 2, LZX_G3_IDLE = 3 };
 
 template <bool STAMP>
-__global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
+__global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // two workgroups per CU: at most 128 VGPRs
 k_pb_gather3(const uint4 *__restrict__ recs /*[n_items][8][2]: beg, end, row0, rows | rep, part slot or ~0, kind, -*/, u32 n_items, u32 *queue,
              u32 qbase, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
              double *item_dot, unsigned long long *stamps)
@@ -821,15 +848,11 @@ k_pb_gather3(const uint4 *__restrict__ recs /*[n_items][8][2]: beg, end, row0, r
     double *fscr = wsum + WAVES;                         // [LZX_PB_GATHER_BLOCK] fold scratch (+ the one-row sum)
     u32 *tick = reinterpret_cast<u32 *>(fscr + LZX_PB_GATHER_BLOCK);   // [2]
 
-    if (tid == 0) {
-        const u32 t0 = atomicAdd(queue, 1u) - qbase;
-        tick[0] = t0;
-        tick[1] = t0 < n_items ? atomicAdd(queue, 1u) - qbase : 0xffffffffu;
-    }
-    __syncthreads();
-    u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)tick[0]);
-    u32 nxt = (u32)__builtin_amdgcn_readfirstlane((int)tick[1]);
-    __syncthreads();
+    // the first two items of a workgroup are its index and its index + grid size (no round trip before the first value is
+    // requested: on the 1 M-vertex graph a workgroup has one item and two dependent atomics were a third of its time); the
+    // counter hands out the items from 2 * grid on
+    u32 cur = blockIdx.x, nxt = blockIdx.x + gridDim.x;
+    const u32 qoff = qbase - 2u * gridDim.x;          // ticket = counter value - qoff
     if (cur < n_items) {
         // (records come through the scalar cache -- the array is read-only and the address wave-uniform; the compiler waits
         //  for a scalar load where it issues it, so the next record costs one scalar round trip per item instead of the static
@@ -994,16 +1017,44 @@ k_pb_gather3(const uint4 *__restrict__ recs /*[n_items][8][2]: beg, end, row0, r
                         atomicAdd(&ytile[sv[u] >> 16], av[u].y);
                     }
                 }
-                for (; kb < blocks; kb += WAVES) {
-                    const u32 p = beg + kb * 128u + lane * 2;
-                    const double2 a = *reinterpret_cast<const double2 *>(val + p);
-                    const u32 sl = *reinterpret_cast<const u32 *>(lslot + p);
-                    atomicAdd(&ytile[sl & 0xffffu], a.x);
-                    atomicAdd(&ytile[sl >> 16], a.y);
+                {   // up to seven more blocks of this wavefront and (wavefront 0) the band's tail of < 128 values: ALL requested
+                    // before the first add -- one block per round trip here was 3.5 serial round trips per item on average,
+                    // a sixth of an item's streaming time on the 10 M-vertex graph
+                    double2 av[7];
+                    u32 sv[7];
+                    double tv[2] = {0.0, 0.0};
+                    u32 ts[2] = {LZX_PB_RB, LZX_PB_RB};
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        if (kb + u * WAVES < blocks) {           // wave-uniform
+                            const u32 p = beg + (kb + u * WAVES) * 128u + lane * 2;
+                            av[u] = *reinterpret_cast<const double2 *>(val + p);
+                            sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                        }
+                    }
+                    if (wv == 0) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const u32 i = beg + blocks * 128u + lane + u * 64;
+                            if (i < end) {
+                                tv[u] = val[i];
+                                ts[u] = lslot[i];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) {
+                        if (kb + u * WAVES < blocks) {
+                            atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
+                            atomicAdd(&ytile[sv[u] >> 16], av[u].y);
+                        }
+                    }
+                    if (wv == 0) {
+                        atomicAdd(&ytile[ts[0]], tv[0]);
+                        __builtin_amdgcn_wave_barrier();   // the tail goes 64 consecutive values per instruction, in order
+                        atomicAdd(&ytile[ts[1]], tv[1]);
+                    }
                 }
-                // the band's tail (< 128 values): 64 consecutive values per instruction, wavefront 0
-                if (wv == 0)
-                    for (u32 i = beg + blocks * 128u + lane; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
                 GSTAMP(t_stream);
                 __syncthreads();
                 GSTAMP(t_bar);
@@ -1059,7 +1110,7 @@ k_pb_gather3(const uint4 *__restrict__ recs /*[n_items][8][2]: beg, end, row0, r
             // the item's alpha partial: wavefronts in order; the next ticket travels with the same barrier
             dot = wave_sum_pb(dot);
             if (lane == 0) wsum[wv] = dot;
-            if (tid == 0) tick[0] = have_next ? t2 - qbase : 0xffffffffu;
+            if (tid == 0) tick[0] = have_next ? t2 - qoff : 0xffffffffu;
             __syncthreads();
             double sdot = 0.0;
             if (tid == 0)
@@ -2574,7 +2625,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         hipLaunchKernelGGL(k_pb_gather3<true>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds3, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_grec), c->pb_g3_items, c->d_pb_gqueue, c->pb_gq_base, c->d_pb_lrow,
                            c->d_pb_val, v, q_loc, c->d_pb_part, c->d_pb_item_dot, c->d_pb_gstamps);
-        c->pb_gq_base += c->pb_g3_items + c->pb_gather_grid;
+        c->pb_gq_base += c->pb_g3_items - c->pb_gather_grid;
     } else if (c->pb_stamps_opt > 0 && c->d_pb_gstamps) {
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_pb_gather<true>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
@@ -2586,7 +2637,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         hipLaunchKernelGGL(k_pb_gather3<false>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds3, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_grec), c->pb_g3_items, c->d_pb_gqueue, c->pb_gq_base, c->d_pb_lrow,
                            c->d_pb_val, v, q_loc, c->d_pb_part, c->d_pb_item_dot, nullptr);
-        c->pb_gq_base += c->pb_g3_items + c->pb_gather_grid;   // what the launch advances the ticket counter by
+        c->pb_gq_base += c->pb_g3_items - c->pb_gather_grid;   // what the launch advances the ticket counter by (below)
     } else
     hipLaunchKernelGGL(k_pb_gather<false>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                        reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,

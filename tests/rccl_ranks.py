@@ -27,9 +27,14 @@ ref = shift_weights(O, a_ref, b_ref, xn_ref) @ Q_ref
 x = np.random.default_rng(9).random(n)
 y_ref = O.spmv(rp, ci, x)
 ok = True
+# the safest forms first (single all-gather), then the two-chunk exchange -- over RCCL it is on request only until this very
+# script has passed once on two or more GPUs -- dense, then with the sparse second chunk (grouped ncclSend / ncclRecv on the
+# exchange stream's own communicator; its send / receive counts were checked pairwise when the graph was reshaped)
 for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=1024, overlap_exchange=0),
-             dict(propagation_blocking=1, hub_entries=1024, sparse_exchange=0), dict(propagation_blocking=1, hub_entries=1024),
-             dict(propagation_blocking=1, hub_entries=1024, lazy_normalisation=0)):
+             dict(propagation_blocking=1, hub_entries=1024, overlap_exchange=1, sparse_exchange=0),
+             dict(propagation_blocking=1, hub_entries=1024, overlap_exchange=1, sparse_exchange=1),
+             dict(propagation_blocking=1, hub_entries=1024, overlap_exchange=1, lazy_normalisation=0),
+             dict(propagation_blocking=0, reorthogonalise=1), dict(propagation_blocking=1, hub_entries=1024, basis_fp32=1)):
     eng = pkg.Engine(local, **mode)
     uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
     if rank == 0:
@@ -43,7 +48,7 @@ for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entr
     a, b, Q, xn, st = eng.lanczos(x0, k)
     check_leading_coefficients(a, b, a_ref, b_ref, ("rccl", world, mode), n=n)
     check_recurrence(O, rp, ci, a, b, Q, ("rccl", world, mode))
-    assert rel_inf(eng.multout(shift_weights(O, a, b, xn)), ref) <= REL_INF_TOL, mode
+    assert rel_inf(eng.multout(shift_weights(O, a, b, xn)), ref) <= (1e-6 if mode.get("basis_fp32") else REL_INF_TOL), mode
     if rank == 0:
         print(f"[rccl_ranks] world={world} {mode}: exchange_recv={gi['exchange_recv']} chunk0={gi['exchange_chunk0']} "
               f"loop {st['loop_ms']:.2f} ms (comm {st['comm_ms']:.2f})", flush=True)

@@ -100,9 +100,12 @@ def test_csr_validation(pkg):
     with pytest.raises(pkg.LzxError):
         fresh.set_option("no_such_option", 1)
     with pytest.raises(pkg.LzxError):
-        fresh.set_option("pb_reduce", 1)                         # an experiment knob: liblzx_dbg.so only
+        fresh.set_option("phase_mask", 3)                        # an experiment knob: liblzx_dbg.so only
+    with pytest.raises(pkg.LzxError):                            # ... also through the product's test-only shape entry
+        pkg._check(fresh.L.lzx_test_set_shape(fresh.h, b"phase_mask", 3), "lzx_test_set_shape", fresh.L)
+    fresh.set_option("pb_reduce", 1)                             # a table SHAPE: served by liblzx.so itself (lzx_test_set_shape)
     fresh.close()
-    dbg = pkg.Engine(0, pb_reduce=1)                             # ... which the package loads when asked for one
+    dbg = pkg.Engine(0, phase_mask=3)                            # an experiment knob makes the package load the debug library
     assert dbg.L is not eng.L
     dbg.close()
     with pytest.raises(pkg.LzxError):

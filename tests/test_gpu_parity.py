@@ -413,7 +413,13 @@ def test_rccl_world1(oracle, pkg):
     rp, ci = O.gen_er(300000, 1500000, 5)
     n = len(rp) - 1
     x = np.random.default_rng(4).random(n)
+    # (over RCCL the two-chunk exchange is on request only, until it has run on two or more physical GPUs)
     eng = pkg.Engine(0, exchange_at_world_1=1, propagation_blocking=1, hub_entries=1024)
+    eng.comm_init_rank(pkg.Engine.unique_id(), 0, 1)
+    eng.set_graph_csr(rp, ci)
+    assert eng.info()["exchange_chunk0"] == 0 and eng.info()["pb_entries"] > 0
+    eng.close()
+    eng = pkg.Engine(0, exchange_at_world_1=1, propagation_blocking=1, hub_entries=1024, overlap_exchange=1, sparse_exchange=1)
     eng.comm_init_rank(pkg.Engine.unique_id(), 0, 1)
     eng.set_graph_csr(rp, ci)
     assert eng.info()["exchange_chunk0"] > 0 and eng.info()["pb_entries"] > 0
