@@ -47,43 +47,24 @@ def test_c2_full_size(pkg, oracle):
     eng.close()
 
 
-def test_c2_k50_against_oracle(pkg, oracle):
-    """BASELINE C2 at its own Krylov dimension, k = 50, against the oracle.  lambda_max of this graph is ~1e3, so e^A x
-    overflows fp64 (as the reference's own dense runs report NaN); the criterion is checked on e^(A - theta_max) x =
-    e^A x / e^theta_max, the exponent shifted by the largest Ritz value on both sides, and on the functional
-    e^(s (A - theta_max)) x with s theta_max = 40 (test_gpu_parity.shift_weights).  Fifty steps without
-    re-orthogonalisation on this graph are NOT reproducible to 1e-10 by the serial/ algorithm itself: the oracle run
-    on the same graph with its vertices relabelled (identical mathematics, other summation orders) differs from the
-    oracle by 3e-8 / 8e-10 in these two quantities (alpha_1 already by 6e-12 relative).  So the tolerance is the north
-    star's 1e-10 or four times the oracle's own relabelling difference, whichever is larger -- measured here, not
-    assumed -- and every one of the 50 columns of the basis is pinned by the three-term recurrence against the
-    ORACLE's SpMV at 1e-12."""
-    from test_gpu_parity import REL_INF_TOL, check_recurrence, rel_inf, shift_weights
+def test_c2_k50_recurrence(pkg, oracle):
+    """BASELINE C2 at its own Krylov dimension, k = 50: every one of the 50 columns of the basis satisfies the three-term
+    recurrence against the ORACLE's SpMV at 1e-12 and has unit norm, and the leading coefficients are the oracle's.  What
+    the centrality vector is worth at k = 50 -- where the serial/ algorithm itself is 3e-8 from the exact-arithmetic answer
+    -- is judged against the extended-precision referee in tests/test_gpu_referee.py (round 2 compared with four times the
+    oracle's own relabelling noise here: a bound that could not tell a correct engine from a worse one)."""
+    from test_gpu_parity import check_leading_coefficients, check_recurrence
     O = oracle
     eng = pkg.Engine(0)
     eng.gen_rmat(20, 1 << 20, 20_000_000, 1234)
     rp, ci = eng.get_graph_csr()
     n, k = 1 << 20, 50
-    a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, np.ones(n), q_colmajor=True)
-    # the oracle against itself: same graph, vertices relabelled by a seeded permutation
-    perm = np.random.default_rng(1).permutation(n).astype(np.uint64)
-    rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp.astype(np.int64)))
-    rp2, ci2 = O.csr_from_keys(n, (perm[rows] << np.uint64(32)) | perm[ci.astype(np.int64)])
-    a_p, b_p, Q_p, xn_p = O.lanczos(rp2, ci2, k, np.ones(n), q_colmajor=True)
+    a_ref, b_ref, _, xn_ref = O.lanczos(rp, ci, 4, np.ones(n), want_q=False)
     a, b, Q, xn, st = eng.lanczos(np.ones(n), k)
     assert xn == xn_ref and st["iters"] == k
     assert np.isfinite(a).all() and np.isfinite(b).all()
+    check_leading_coefficients(a[:4], b[:3], a_ref, b_ref, "c2_k50", n=n)
     check_recurrence(O, rp, ci, a, b, Q, "c2_k50")
-    for cap in (None, 40.0):
-        ref = shift_weights(O, a_ref, b_ref, xn_ref, cap=cap) @ Q_ref
-        assert np.isfinite(ref).all() and np.abs(ref).max() > 0
-        own = rel_inf((shift_weights(O, a_p, b_p, xn_p, cap=cap) @ Q_p)[perm.astype(np.int64)], ref)
-        tol = max(REL_INF_TOL, 4.0 * own)
-        got_host = rel_inf(shift_weights(O, a, b, xn, cap=cap) @ Q, ref)
-        got_dev = rel_inf(eng.multout(shift_weights(O, a, b, xn, cap=cap)), ref)
-        print(f"C2 k=50 cap={cap}: oracle vs relabelled oracle {own:.2e}; engine vs oracle {got_host:.2e} (host multOut) "
-              f"{got_dev:.2e} (device multOut); tolerance {tol:.1e}")
-        assert got_host <= tol and got_dev <= tol, (cap, own, got_host, got_dev)
     eng.close()
 
 
