@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 
 #include "lzx_internal.h"
 
@@ -316,17 +317,23 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
         c->k_prep = 0;
     }
 
-    // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161).
+    // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161) -- one dependent chain of
+    // n additions (7 ms at n = 10 M), on a helper thread while this one sizes the basis, clears it and uploads x0 (a pageable
+    // copy that blocks its caller for about as long)
     double ss = 0.0;
-    for (u64 i = 0; i < n; ++i) ss += x0[i] * x0[i];
-    const double x_norm = std::sqrt(ss);
-    if (x_norm_out) *x_norm_out = x_norm;
+    struct Joiner {
+        std::thread t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } norm_thread{std::thread([&ss, x0, n]() {
+        double acc = 0.0;
+        for (u64 i = 0; i < n; ++i) acc += x0[i] * x0[i];
+        ss = acc;
+    })};
 
     for (lzx_ctx *c : cs) {
         LZX_TRY(ensure_capacity(c, k));
         c->k_last = c->k_done = 0;
         c->ymon_valid = 0;
-        double *col0 = basis_col(c, 0);
         if (c->qf32) {
             for (double *r : c->d_ring) LZX_HIP(hipMemsetAsync(r, 0, sizeof(double) * c->ldq, c->stream));
         } else {
@@ -337,6 +344,13 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
                 LZX_HIP(hipMemset2DAsync(c->d_Q + c->ldq + c->n_loc_pad, sizeof(double) * c->ldq, 0, sizeof(double) * LZX_TAIL, k - 1, c->stream));
         }
         LZX_HIP(hipMemcpyAsync(c->d_io, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    norm_thread.t.join();
+    const double x_norm = std::sqrt(ss);
+    if (x_norm_out) *x_norm_out = x_norm;
+    for (lzx_ctx *c : cs) {
+        LZX_HIP(hipSetDevice(c->device));
+        double *col0 = basis_col(c, 0);
         // q_0 = x0 / ||x0|| (serial/lib/lanczos.cc:16-17), scattered into the internal order
         if (!multi) {
             LZX_TRY(lzx_launch_permute_in(c, c->d_io, col0, x_norm));
