@@ -170,116 +170,59 @@ def main():
             return None, 0.0
         return e, time.perf_counter() - t
 
-    # Several ranks: the exchange can run as one all-gather before a plain SpMV, or as two chunks overlapping the
-    # blocked SpMV.  Which is faster depends on the node's xGMI and on the rank count, so both
-    # are timed for a few untimed iterations and every rank adopts the faster one (max over ranks decides).
-    tune = {}
-    if world == 1 and not rehearse:
-        eng, t_gen = make_engine()
-        if eng is None:
-            sys.exit("bench.py: could not build the engine")
-    else:
-        def timed(e):
-            best = float("inf")
-            for _ in range(2):
-                e.lanczos_prepare(np.ones(n), 6)
-                e.sync()
-                dist.barrier()
-                t = time.perf_counter()
-                e.lanczos_run()
-                dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                best = min(best, float(dt.item()))
-            return best / 6 * 1e3
-
-        eng, t_gen = make_engine(overlap_exchange=0)
-        if eng is None:
-            sys.exit(f"bench.py rank {rank}: could not build the engine (see stderr of the failing rank)")
-        tune["single"] = timed(eng)
-        # The overlapped mode is asked for explicitly (over RCCL it is off by default until it has run on >= 2 GPUs).  What
-        # can go wrong there is an exception (handled below: every rank falls back) or a collective that never completes:
-        # for that a watchdog thread ends THIS process with a non-zero code (every rank has one; a rank that is not stuck
-        # itself gets stuck in the next collective and its own watchdog fires) -- the run fails fast and visibly instead of
-        # sitting in the driver's time limit.  Nothing is re-executed from a GPU process.
-        import threading
-        trial_done = threading.Event()
-
-        def watchdog(limit_s=float(os.environ.get("LZX_BENCH_TRIAL_LIMIT_S", "120"))):
-            if not trial_done.wait(limit_s):
-                print(f"[bench rank {rank}] the overlapped-exchange trial did not finish within {limit_s:.0f} s: giving up "
-                      f"(set overlap_exchange=0 to skip the trial)", file=sys.stderr, flush=True)
-                os._exit(17)
-
-        if os.environ.get("LZX_BENCH_SKIP_OVERLAP_TRIAL") == "1":
-            alt = None
-        else:
-            threading.Thread(target=watchdog, daemon=True).start()
-            alt, _ = make_engine(overlap_exchange=1, sparse_exchange=1)
-        # a rank count / graph that does not qualify for the overlapped mode on some rank: nothing to compare
-        if alt is not None and all_ok(bool(alt.info()["pb_entries"])):
-            # the two-chunk exchange (second chunk sparse: grouped ncclSend / ncclRecv) has only ever run in-process
-            # before the first real multi-GPU run: an error on any rank keeps every rank on the single all-gather
-            t_alt, ok = float("inf"), True
-            try:
-                t_alt = timed(alt)
-            except Exception as exc:
-                print(f"[bench rank {rank}] overlapped exchange failed: {exc}", file=sys.stderr, flush=True)
-                ok = False
-            if all_ok(ok):
-                tune["overlapped"] = t_alt
-                tune["overlapped_received_MB_per_rank"] = 8e-6 * alt.info()["exchange_recv"]
-                if tune["overlapped"] < tune["single"]:
-                    eng.close()
-                    eng, alt = alt, None
-        if alt is not None:
-            alt.close()
-        trial_done.set()
-    gi = eng.info()
-
-    def barrier():
-        eng.sync()
+    def barrier(e):
+        e.sync()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
     x0 = np.ones(n)
-    if W > 0:
-        eng.lanczos_prepare(x0, W)
-        eng.lanczos_run()
-    t_in = time.perf_counter()
-    eng.lanczos_prepare(x0, K)   # x0 uploaded, q_0 in HBM: inputs resident before the clock starts
-    barrier()
-    t_in = time.perf_counter() - t_in
-    t0 = time.perf_counter()
-    st = eng.lanczos_run()       # exactly K iterations; returns after a stream synchronise
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        agg = torch.tensor([st["spmv_ms"], float(st["spmv_bytes"]), st["comm_ms"], st["vec_ms"]],
-                           dtype=torch.float64, device="cuda")
-        mx = agg.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        spmv_ms_max, comm_ms, vec_ms = float(mx[0]), float(mx[2]), float(mx[3])
-        spmv_bytes_total = float(agg[1])
-    else:
-        spmv_ms_max, comm_ms, vec_ms = st["spmv_ms"], st["comm_ms"], st["vec_ms"]
-        spmv_bytes_total = float(st["spmv_bytes"])
 
-    t_out = time.perf_counter()
-    alpha, beta, _ = eng.lanczos_fetch(K)
-    t_out = time.perf_counter() - t_out
-    finite = bool(np.isfinite(alpha).all() and np.isfinite(beta).all())
+    def measure(e):
+        """W untimed iterations, then exactly K timed ones between barrier + synchronise on both sides, max over ranks."""
+        if W > 0:
+            e.lanczos_prepare(x0, W)
+            e.lanczos_run()
+        t_in = time.perf_counter()
+        e.lanczos_prepare(x0, K)     # x0 uploaded, q_0 in HBM: inputs resident before the clock starts
+        barrier(e)
+        t_in = time.perf_counter() - t_in
+        t0 = time.perf_counter()
+        st = e.lanczos_run()         # exactly K iterations; returns after a stream synchronise
+        barrier(e)
+        elapsed = time.perf_counter() - t0
+        m = {}
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            agg = torch.tensor([st["spmv_ms"], float(st["spmv_bytes"]), st["comm_ms"], st["vec_ms"]],
+                               dtype=torch.float64, device="cuda")
+            mx = agg.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            m.update(spmv_ms_max=float(mx[0]), comm_ms=float(mx[2]), vec_ms=float(mx[3]), spmv_bytes_total=float(agg[1]))
+        else:
+            m.update(spmv_ms_max=st["spmv_ms"], comm_ms=st["comm_ms"], vec_ms=st["vec_ms"], spmv_bytes_total=float(st["spmv_bytes"]))
+        t_out = time.perf_counter()
+        alpha, beta, _ = e.lanczos_fetch(K)
+        t_out = time.perf_counter() - t_out
+        m.update(elapsed=elapsed, t_in=t_in, t_out=t_out, finite=bool(np.isfinite(alpha).all() and np.isfinite(beta).all()))
+        return m
 
-    stream = eng.bench_stream(2 << 30, 5) if rank == 0 else (0.0, 0.0)   # 2 GiB: eight times the Infinity Cache
-    if rank == 0:
-        spmv_avg_ms = spmv_ms_max / K
-        achieved = spmv_bytes_total / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
-        out = {
+    stream = None
+
+    def line(e, m, tune):
+        """rank 0's JSON line for measurement m of engine e"""
+        nonlocal stream
+        gi = e.info()
+        if stream is None:
+            stream = e.bench_stream(2 << 30, 5)   # 2 GiB: eight times the Infinity Cache
+        elapsed = m["elapsed"]
+        spmv_avg_ms = m["spmv_ms_max"] / K
+        achieved = m["spmv_bytes_total"] / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
+        return {
             "metric": "lanczos_iterations_per_sec",
             "value": K / elapsed,
             "unit": "iter/s",
@@ -302,13 +245,13 @@ def main():
                              f"vertices that have an edge are exchanged, unnormalised; "
                              + (f"two chunks overlapping the SpMV, the second one sparse: each peer sends only what this rank's rows reference"
                                 if gi.get("exchange_chunk0") else "one all-gather") + ") + 1 two-double all-reduce",
-                "exchange_tuning_ms_per_iter": tune or None,
+                "exchange_tuning_ms_per_iter": dict(tune) or None,
                 "exchange_chunk0_doubles_per_rank": gi.get("exchange_chunk0", 0),
                 "graph_build_s": round(t_gen, 3),
                 # not `value`: the same K iterations with the host hand-over (x0 upload, basis set-up) and the download
                 # of alpha / beta included -- what a caller holding host buffers sees (rank 0's clock)
-                "iters_per_sec_including_host_transfers": K / (elapsed + t_in + t_out),
-                "lanczos_coefficients_finite": finite,
+                "iters_per_sec_including_host_transfers": K / (elapsed + m["t_in"] + m["t_out"]),
+                "lanczos_coefficients_finite": m["finite"],
             },
             "roofline": {
                 "bound": "hbm",
@@ -325,16 +268,99 @@ def main():
                 # the same box's own streaming rates (read-only sum / copy over 1 GiB, rank 0) and the SpMV against them
                 "measured_stream_read_GBps": stream[0], "measured_stream_copy_GBps": stream[1],
                 "frac_of_measured_stream_read": achieved / (stream[0] * world) if stream[0] else None,
-                "algorithmic_bytes_per_spmv": spmv_bytes_total,
+                "algorithmic_bytes_per_spmv": m["spmv_bytes_total"],
                 "avg_spmv_ms": spmv_avg_ms,
-                "spmv_share_of_loop": spmv_ms_max / (elapsed * 1e3),
-                "vector_kernels_ms_per_iter": vec_ms / K,
-                "exchange_ms_per_iter": comm_ms / K,
+                "spmv_share_of_loop": m["spmv_ms_max"] / (elapsed * 1e3),
+                "vector_kernels_ms_per_iter": m["vec_ms"] / K,
+                "exchange_ms_per_iter": m["comm_ms"] / K,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+
+    tune = {}
+    if world == 1 and not rehearse:
+        eng, t_gen = make_engine()
+        if eng is None:
+            sys.exit("bench.py: could not build the engine")
+        out = line(eng, measure(eng), tune)
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng, ge.load_oracle())
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    else:
+        # Several ranks.  The exchange can run as one all-gather before the SpMV, or as two chunks overlapping the blocked
+        # SpMV, the second one sparse.  Which is faster depends on the node's xGMI and on the rank
+        # count; the second has never run on two physical GPUs.  So: (1) the whole measurement -- warm-up, K timed
+        # iterations, rank aggregation -- is done in the single-all-gather mode FIRST and rank 0 holds its line; (2) the
+        # overlapped mode is then tried for a few iterations under a watchdog and, if it is faster on the slowest rank,
+        # measured in full and reported instead.  Whatever happens in (2) -- an error (every rank falls back) or a
+        # collective that never completes (the watchdog prints the held line and ends the process) -- the run still
+        # delivers the line of (1).  Nothing is re-executed from a GPU process.
+        def timed(e):
+            best = float("inf")
+            for _ in range(2):
+                e.lanczos_prepare(x0, 6)
+                e.sync()
+                dist.barrier()
+                t = time.perf_counter()
+                e.lanczos_run()
+                dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                best = min(best, float(dt.item()))
+            return best / 6 * 1e3
+
+        eng, t_gen = make_engine(overlap_exchange=0)
+        if eng is None:
+            sys.exit(f"bench.py rank {rank}: could not build the engine (see stderr of the failing rank)")
+        m_single = measure(eng)
+        tune["single"] = timed(eng)
+        out = line(eng, m_single, tune) if rank == 0 else None
+        import threading
+        trial_done = threading.Event()
+        held = json.dumps(dict(out, config=dict(out["config"], exchange_tuning_ms_per_iter=dict(
+            tune, overlapped="did not finish (watchdog): the line is the single all-gather mode's")))) if rank == 0 else None
+
+        def watchdog(limit_s=float(os.environ.get("LZX_BENCH_TRIAL_LIMIT_S", "120"))):
+            if not trial_done.wait(limit_s):
+                print(f"[bench rank {rank}] the overlapped-exchange trial did not finish within {limit_s:.0f} s: reporting the "
+                      f"single all-gather measurement and leaving (LZX_BENCH_SKIP_OVERLAP_TRIAL=1 skips the trial)",
+                      file=sys.stderr, flush=True)
+                if held is not None:
+                    print(held, flush=True)
+                os._exit(0)
+
+        if os.environ.get("LZX_BENCH_SKIP_OVERLAP_TRIAL") == "1":
+            alt = None
+        else:
+            threading.Thread(target=watchdog, daemon=True).start()
+            alt, _ = make_engine(overlap_exchange=1, sparse_exchange=1)
+        # a rank count / graph that does not qualify for the overlapped mode on some rank: nothing to compare
+        if alt is not None and all_ok(bool(alt.info()["pb_entries"])):
+            t_alt, ok = float("inf"), True
+            try:
+                t_alt = timed(alt)
+            except Exception as exc:
+                print(f"[bench rank {rank}] overlapped exchange failed: {exc}", file=sys.stderr, flush=True)
+                ok = False
+            if all_ok(ok):
+                tune["overlapped"] = t_alt
+                tune["overlapped_received_MB_per_rank"] = 8e-6 * alt.info()["exchange_recv"]
+                if rank == 0:
+                    out["config"]["exchange_tuning_ms_per_iter"] = dict(tune)
+                if tune["overlapped"] < tune["single"]:
+                    m_alt, ok = None, True
+                    try:
+                        m_alt = measure(alt)
+                    except Exception as exc:
+                        print(f"[bench rank {rank}] overlapped exchange failed in the timed run: {exc}", file=sys.stderr, flush=True)
+                        ok = False
+                    if all_ok(ok) and m_alt["elapsed"] < m_single["elapsed"]:
+                        if rank == 0:
+                            out = line(alt, m_alt, tune)
+                        eng.close()
+                        eng, alt = alt, None
+        if alt is not None:
+            alt.close()
+        trial_done.set()
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     eng.close()

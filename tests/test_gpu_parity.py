@@ -431,6 +431,47 @@ def test_rccl_world1(oracle, pkg):
     eng.close()
 
 
+def test_known_answer_eigen_expansion_on_the_device(oracle, engine_factory):
+    """The reference's own accuracy test, serial/tests/numerical_test.cc:74-116 (driver: k in 5..50), on the device:
+    x = sum c_i v_i over 100 known eigenpairs, c_i ~ U(0,1) seed 1234, and the analytic e^A x = sum c_i e^(lambda_i) v_i
+    as the answer -- an answer that owes nothing to the oracle.  The NotreDame_yeast fixtures (n = 2114) are not in the
+    repository: the eigenpairs come from a dense eigh of a seeded graph of that size.  Checked: the reference's recorded
+    error curve (serial/output/numerical_test_output.txt: 2.1 at k = 5, 3.5e-11 at k = 20, 4e-15 at k = 25, floor 3e-15)
+    in shape -- monotone down to a rounding-level floor that is reached by k = 20 and kept to k = 50 -- in plain and in
+    blocked mode, through the device multOut and the host one, and that the engine is never worse than the oracle."""
+    O = oracle
+    n = 2114
+    ks = (5, 10, 15, 20, 25, 30, 40, 50)
+    for gname, (rp, ci) in (("er", O.gen_er(n, 9000, 1234)), ("rmat", O.gen_rmat(12, n, 9000, 1234, a=0.45, b=0.22, c=0.22))):
+        A = np.zeros((n, n))
+        rows = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+        A[rows, ci.astype(np.int64)] = 1.0
+        lam, Vec = np.linalg.eigh(A)
+        c = np.random.default_rng(1234).random(100)
+        top = Vec[:, -100:]
+        x = top @ c
+        exact = top @ (c * np.exp(lam[-100:]))                   # lambda_max = 9.5 / 26: e^A x itself is representable
+        for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=64)):
+            eng = engine_factory(**mode)
+            eng.set_graph_csr(rp, ci)
+            errs, errs_orc = [], []
+            for k in ks:
+                a, b, Q, xn, st = eng.lanczos(x, k)
+                lk, V = O.eigen(a, b)
+                t = V @ (np.exp(lk) * (xn * V[0, :]))
+                dev = eng.multout(t)
+                assert rel_inf(t @ Q, dev) <= 1e-13
+                errs.append(np.linalg.norm(dev - exact) / np.linalg.norm(exact))   # the reference's measure (check_ans)
+                ar, br, Qr, xr = O.lanczos(rp, ci, k, x, q_colmajor=True)
+                lr, Vr = O.eigen(ar, br)
+                errs_orc.append(np.linalg.norm((Vr @ (np.exp(lr) * (xr * Vr[0, :]))) @ Qr - exact) / np.linalg.norm(exact))
+            print(gname, mode, " ".join(f"k={k}: {e:.1e} ({eo:.1e})" for k, e, eo in zip(ks, errs, errs_orc)))
+            assert errs[0] > 1e-4 and errs[0] > errs[1] > errs[2]
+            assert max(errs[3:]) < 1e-12, errs                   # the floor, reached by k = 20 and kept to k = 50
+            assert all(e <= 2.0 * eo + 1e-13 for e, eo in zip(errs, errs_orc)), (errs, errs_orc)
+            eng.close()
+
+
 def test_general_csr_patterns(oracle, engine_factory):
     """The C ABI takes any pattern-only CSR, not only what the reference's loader produces: non-symmetric, columns in
     any order, duplicate entries (each one counts), self-loops, empty rows -- plain and blocked SpMV agree with the

@@ -13,7 +13,7 @@ src = pkg.Engine(0, propagation_blocking=0)
 src.gen_rmat(scale, n, draws, 1234)
 rp, ci = src.get_graph_csr()
 src.close()
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("RANK_PROBE_WORLDS", "1,2,4,8").split(",")]:
     for opts in (dict(propagation_blocking=0), dict(sparse_exchange=0), dict()):
         if world == 1:
             eng = pkg.Engine(0, **opts)
