@@ -1088,6 +1088,55 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
     *avg_ms = total / reps;
     if (min_ms) *min_ms = best;
 #ifdef LZX_DEBUG_KNOBS
+    if (const char *rt = getenv("LZX_RELOC_TEST")) {
+        // Does the SpMV's time depend on WHERE its big streamed arrays lie?  Each array named in the variable (v: the value
+        // stream, s: its slots, c: the reduced codes) is moved to a fresh allocation at a series of offsets and the SpMV timed
+        // with everything else in place (the "fast" / "slow" process states of DESIGN.md 3.1 i).
+        auto time_spmv = [&](double *avg, double *mn) -> int {
+            double tot = 0.0, best = 1e300;
+            for (int r = 0; r < 8; ++r) {
+                LZX_HIP(hipEventRecord(c->ev_a, c->stream));
+                LZX_TRY(lzx_launch_spmv(c, l));
+                LZX_HIP(hipEventRecord(c->ev_b, c->stream));
+                LZX_HIP(hipEventSynchronize(c->ev_b));
+                float ms = 0.f;
+                LZX_HIP(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+                tot += ms;
+                if (ms < best) best = ms;
+            }
+            *avg = tot / 8;
+            *mn = best;
+            return LZX_OK;
+        };
+        const size_t offs[] = {0, 256, 4096, 65536, 1u << 20, (1u << 20) + 4096, 2u << 20, (3u << 20) + 65536, 16u << 20, (32u << 20) + 3 * 4096,
+                               (5u << 20) + 512, 48u << 20};
+        const size_t pad = 64u << 20;
+        for (const char *w = rt; *w && c->pb && c->pb_values; ++w) {
+            void **slot = nullptr;
+            size_t bytes = 0;
+            if (*w == 'v') { slot = reinterpret_cast<void **>(&c->d_pb_val); bytes = sizeof(double) * (c->pb_values + 8); }
+            else if (*w == 's') { slot = reinterpret_cast<void **>(&c->d_pb_lrow); bytes = sizeof(uint16_t) * (c->pb_values + 8); }
+            else if (*w == 'c' && c->pbr_steps) { slot = reinterpret_cast<void **>(&c->d_pbr_code); bytes = sizeof(uint4) * ((size_t)c->pbr_steps * 64 + 1); }
+            if (!slot || !*slot) continue;
+            char *buf = nullptr;
+            LZX_HIP(hipMalloc(&buf, bytes + pad));
+            void *orig = *slot;
+            double a0 = 0, m0 = 0;
+            LZX_TRY(time_spmv(&a0, &m0));
+            fprintf(stderr, "[lzx reloc] %c at %p (%zu MB): spmv avg %.4f min %.4f ms; moved to %p + offset:\n", *w, orig, bytes >> 20, a0, m0, (void *)buf);
+            for (size_t off : offs) {
+                LZX_HIP(hipMemcpyAsync(buf + off, orig, bytes, hipMemcpyDeviceToDevice, c->stream));
+                *slot = buf + off;
+                double a = 0, m = 0;
+                int rc = time_spmv(&a, &m);
+                *slot = orig;
+                LZX_TRY(rc);
+                fprintf(stderr, "[lzx reloc]   %c + %9zu: avg %.4f min %.4f ms\n", *w, off, a, m);
+            }
+            LZX_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(buf);
+        }
+    }
     if (getenv("LZX_TRACE_SPMV")) {
         // one more SpMV with marks between its kernels: hub/body, split-row finish, scatter, gather (+finish)
         for (auto &ev : c->trace_ev)
