@@ -1175,20 +1175,22 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
             LZX_HIP(hipMemcpy(h.data(), c->d_pb_gstamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
             unsigned long long t0 = ~0ull;
             for (u32 w = 0; w < G; ++w) if (h[8 * w + 1]) t0 = std::min(t0, h[8 * w]);
-            std::vector<double> en, zr, sm, br, fd, rate;
+            std::vector<double> en, zr, sm, br, fd, rate, clk;
             double items = 0, vals = 0;
             for (u32 w = 0; w < G; ++w) {
                 const unsigned long long *r = &h[8 * (size_t)w];
                 if (!r[1]) continue;
                 en.push_back((r[1] - t0) * 0.01); zr.push_back(r[2] * 0.01); sm.push_back(r[3] * 0.01); br.push_back(r[4] * 0.01); fd.push_back(r[5] * 0.01);
-                items += (double)r[6]; vals += (double)r[7];
+                items += (double)(r[6] & 0xffffull); vals += (double)r[7];
+                if (r[1] > r[0]) clk.push_back((double)(r[6] >> 16) / ((double)(r[1] - r[0]) * 10.0));   // shader cycles per ns = GHz
                 if (r[3]) rate.push_back((double)r[7] * 10.0 / (r[3] * 0.01) * 1e-3);   // GB/s while streaming (wavefront 0's clock; group items: its own band)
             }
             auto srt = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); };
-            srt(en); srt(zr); srt(sm); srt(br); srt(fd); srt(rate);
+            srt(en); srt(zr); srt(sm); srt(br); srt(fd); srt(rate); srt(clk);
             auto pct = [](const std::vector<double> &v, double p) { return v.empty() ? 0.0 : v[(size_t)(p * (v.size() - 1))]; };
             fprintf(stderr, "[lzx gstamps] gather: %zu workgroups, %.0f items, %.0f values | end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f\n", en.size(), items, vals,
                     en.front(), pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), en.back());
+            fprintf(stderr, "[lzx gstamps]   in-kernel shader clock (s_memtime / s_memrealtime), GHz: p10 %.3f p50 %.3f p90 %.3f\n", pct(clk, 0.1), pct(clk, 0.5), pct(clk, 0.9));
             fprintf(stderr, "[lzx gstamps]   wavefront 0, us per workgroup (p10 / p50 / p90): records+zeroing %.1f / %.1f / %.1f | streaming %.1f / %.1f / %.1f | barrier before fold %.1f / %.1f / %.1f | fold %.1f / %.1f / %.1f | GB/s per workgroup while streaming p50 %.1f\n",
                     pct(zr, 0.1), pct(zr, 0.5), pct(zr, 0.9), pct(sm, 0.1), pct(sm, 0.5), pct(sm, 0.9), pct(br, 0.1), pct(br, 0.5), pct(br, 0.9),
                     pct(fd, 0.1), pct(fd, 0.5), pct(fd, 0.9), pct(rate, 0.5));

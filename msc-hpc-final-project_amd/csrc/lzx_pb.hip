@@ -530,7 +530,7 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
 // its own y tile; the tiles are folded in wavefront order.
 // STAMP (debug library, option pb_stamps): wavefront 0 of every workgroup keeps 100 MHz time stamps per section --
 // stamps[8 * workgroup ..]: start, end, ticks zeroing tiles + reading item records, ticks streaming, ticks in barriers
-// before the fold, ticks folding, items, values.
+// before the fold, ticks folding, items | s_memtime cycles << 16, values.
 template <bool STAMP>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
 k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *band_rep, const u32 *band_beg,
@@ -540,7 +540,8 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     unsigned long long t_start = 0, t_mark = 0, t_zero = 0, t_stream = 0, t_bar = 0, t_fold = 0, n_vals = 0;
     u32 n_it = 0;
 #define GSTAMP(acc) do { if (STAMP) { const unsigned long long t_ = wall_clock64(); acc += t_ - t_mark; t_mark = t_; } } while (0)
-    if (STAMP) t_start = t_mark = wall_clock64();
+    unsigned long long c_start = 0;
+    if (STAMP) { t_start = t_mark = wall_clock64(); c_start = __builtin_amdgcn_s_memtime(); }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
     constexpr u32 TILE = LZX_PB_RB + 8;                  // + spare slot for padding entries
@@ -777,7 +778,9 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     }   // batches of MAXR rounds
     if (STAMP && tid == 0) {
         unsigned long long *o = stamps + 8 * (size_t)blockIdx.x;
-        o[0] = t_start; o[1] = wall_clock64(); o[2] = t_zero; o[3] = t_stream; o[4] = t_bar; o[5] = t_fold; o[6] = n_it; o[7] = n_vals;
+        o[0] = t_start; o[1] = wall_clock64(); o[2] = t_zero; o[3] = t_stream; o[4] = t_bar; o[5] = t_fold;
+        o[6] = (unsigned long long)n_it | ((__builtin_amdgcn_s_memtime() - c_start) << 16);   // items | shader-clock cycles: the clock the kernel ran at
+        o[7] = n_vals;
     }
 #undef GSTAMP
     dot = wave_sum_pb(dot);
