@@ -21,7 +21,7 @@ PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "s
 
 # test-only shapes the product library accepts through lzx_test_set_shape (csrc/lzx_test_hooks.h): they select among code
 # paths the product contains (what large graphs get by themselves), so tests that force them still run liblzx.so
-SHAPE_OPTIONS = ("pb_reduce", "pb_target", "pb_unit", "pb_column_band", "pb_run_align", "pb_taper", "pb_group", "pb_group_force",
+SHAPE_OPTIONS = ("pb_reduce", "pb_target", "pb_unit", "pb_column_band", "pb_run_align", "pb_taper", "pb_dyn_share", "pb_gather_grid", "pb_group", "pb_group_force",
                  "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -113,6 +113,8 @@ def _load(path: str, mode: int) -> ctypes.CDLL:
         fn.argtypes = args
     L.lzx_test_set_shape.restype = ctypes.c_int       # test hook, not in include/lzx.h
     L.lzx_test_set_shape.argtypes = [_h, ctypes.c_char_p, ctypes.c_int64]
+    L.lzx_test_get_shape.restype = ctypes.c_int
+    L.lzx_test_get_shape.argtypes = [_h, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
     return L
 
 
@@ -159,6 +161,12 @@ class Engine:
             _check(self.L.lzx_test_set_shape(self.h, name.encode(), int(value)), f"lzx_test_set_shape({name})", self.L)
             return
         _check(self.L.lzx_set_option(self.h, name.encode(), int(value)), f"lzx_set_option({name})", self.L)
+
+    def shape(self, name: str) -> int:
+        """what shape the blocked tables took (test hook lzx_test_get_shape): gather_items_dealt / _drawn, gather_workgroups"""
+        v = ctypes.c_int64()
+        _check(self.L.lzx_test_get_shape(self.h, name.encode(), ctypes.byref(v)), f"lzx_test_get_shape({name})", self.L)
+        return int(v.value)
 
     def close(self):
         if self.h:

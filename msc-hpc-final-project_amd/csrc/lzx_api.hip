@@ -123,6 +123,8 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_reduce")) c->pb_reduce_opt = value;
     else if (!strcmp(name, "pb_unit")) c->pb_unit_opt = value;
     else if (!strcmp(name, "pb_taper")) c->pb_taper_opt = value;
+    else if (!strcmp(name, "pb_dyn_share")) c->pb_dyn_opt = value;
+    else if (!strcmp(name, "pb_gather_grid")) c->pb_grid_cap_opt = value;
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "pb_persistent")) c->pb_persist_opt = value;
@@ -163,6 +165,8 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "pb_taper")) c->pb_taper_opt = value;
+    else if (!strcmp(name, "pb_dyn_share")) c->pb_dyn_opt = value;
+    else if (!strcmp(name, "pb_gather_grid")) c->pb_grid_cap_opt = value;
     else if (!strcmp(name, "pb_group")) c->pb_group_opt = value;
     else if (!strcmp(name, "pb_group_force")) c->pb_group_force_opt = value;
     else if (!strcmp(name, "narrow_slices")) c->narrow_opt = value;
@@ -171,6 +175,18 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "item_len")) c->item_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_set_shape: unknown shape '%s'", name);
+    return LZX_OK;
+}
+
+// what shape the blocked tables took (test hook, beside lzx_test_set_shape): "gather_items_dealt", "gather_items_drawn",
+// "gather_workgroups"
+extern "C" int lzx_test_get_shape(lzx_handle c, const char *name, int64_t *value)
+{
+    if (!c || !name || !value) LZX_FAIL(LZX_ERR_ARG, "lzx_test_get_shape: bad argument");
+    if (!strcmp(name, "gather_items_dealt")) *value = c->pb ? c->pb_n_static : 0;
+    else if (!strcmp(name, "gather_items_drawn")) *value = c->pb ? c->pb_n_dyn : 0;
+    else if (!strcmp(name, "gather_workgroups")) *value = c->pb ? c->pb_gather_grid : 0;
+    else LZX_FAIL(LZX_ERR_ARG, "lzx_test_get_shape: unknown shape '%s'", name);
     return LZX_OK;
 }
 
@@ -1190,6 +1206,16 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
             auto pct = [](const std::vector<double> &v, double p) { return v.empty() ? 0.0 : v[(size_t)(p * (v.size() - 1))]; };
             fprintf(stderr, "[lzx gstamps] gather: %zu workgroups, %.0f items, %.0f values | end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f\n", en.size(), items, vals,
                     en.front(), pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), en.back());
+            {   // the workgroups that end last: what did they do?
+                std::vector<u32> idx;
+                for (u32 w = 0; w < G; ++w) if (h[8 * (size_t)w + 1]) idx.push_back(w);
+                std::sort(idx.begin(), idx.end(), [&](u32 a, u32 b) { return h[8 * (size_t)a + 1] > h[8 * (size_t)b + 1]; });
+                for (size_t q = 0; q < idx.size(); q += (q < 8 ? 1 : idx.size() / 8)) {
+                    const unsigned long long *r = &h[8 * (size_t)idx[q]];
+                    fprintf(stderr, "[lzx gstamps]   rank %zu: workgroup %u start %.1f end %.1f us | zero %.1f stream %.1f barrier %.1f fold %.1f | items %llu values %llu\n", q, idx[q],
+                            (r[0] - t0) * 0.01, (r[1] - t0) * 0.01, r[2] * 0.01, r[3] * 0.01, r[4] * 0.01, r[5] * 0.01, r[6] & 0xffffull, r[7]);
+                }
+            }
             fprintf(stderr, "[lzx gstamps]   in-kernel shader clock (s_memtime / s_memrealtime), GHz: p10 %.3f p50 %.3f p90 %.3f\n", pct(clk, 0.1), pct(clk, 0.5), pct(clk, 0.9));
             fprintf(stderr, "[lzx gstamps]   wavefront 0, us per workgroup (p10 / p50 / p90): records+zeroing %.1f / %.1f / %.1f | streaming %.1f / %.1f / %.1f | barrier before fold %.1f / %.1f / %.1f | fold %.1f / %.1f / %.1f | GB/s per workgroup while streaming p50 %.1f\n",
                     pct(zr, 0.1), pct(zr, 0.5), pct(zr, 0.9), pct(sm, 0.1), pct(sm, 0.5), pct(sm, 0.9), pct(br, 0.1), pct(br, 0.5), pct(br, 0.9),

@@ -58,6 +58,9 @@ static constexpr u32 LZX_PB_TARGET = 32768;   // upper limit of the values per g
 static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
 static constexpr u32 LZX_PB_GROUP = 16384;    // a row band of at most this many values is gathered by one wavefront (k_pb_gather)
+static constexpr u32 LZX_PB_DYN_SHARE = 0;    // per cent of the gather pass's estimated cost whose items are drawn at run time (k_pb_gather's dynamic tail): off --
+                                               // it evens the workgroups' end times out (170-194 us instead of 122-192 on the 10 M-vertex graph) and the pass ends when it did
+                                               // before: its bound is the aggregate streaming rate, early finishers only leave their bandwidth to the others (DESIGN 3.1 j)
 static constexpr u32 LZX_PB_ITEM_GROUP = 0xfffffffeu, LZX_PB_ITEM_NONE = 0xfffffffdu;   // item.w markers (0xffffffff: adds into v)
 // entries, padded entries and values of one rank's blocked tables are indexed with 32 bits (a margin is left for the
 // kernels' look-ahead)
@@ -228,6 +231,10 @@ struct lzx_ctx {
     uint4 *d_pb_grec = nullptr;        // [pb_g3_items][8][2] fat records, longest item first, one per (item, wavefront)
     double *d_pb_item_dot = nullptr;   // [pb_g3_items] alpha partial of every item (closed in item order by k_pb_finish)
     u32 *d_pb_gqueue = nullptr;        // the ticket counter (never reset)
+    u32 pb_n_static = 0, pb_n_dyn = 0; // gather items dealt to workgroups by the host / drawn from d_pb_gcounter at run time (k_pb_gather)
+    u32 *d_pb_gcounter = nullptr;      // the dynamic tail's ticket counter (back to 0 at the end of every launch)
+    int64_t pb_grid_cap_opt = -1;      // test shape pb_gather_grid: at most this many gather workgroups
+    int64_t pb_dyn_opt = -1;           // test shape pb_dyn_share: per cent of the gather pass's cost left to the dynamic tail (-1: default)
     u32 pb_gq_base = 0;                // its value when the next launch starts
     int64_t pb_g3_opt = -1;            // debug knob pb_gather_tickets: 0 = the static longest-first lists (k_pb_gather)
     u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)

@@ -532,9 +532,9 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
 // stamps[8 * workgroup ..]: start, end, ticks zeroing tiles + reading item records, ticks streaming, ticks in barriers
 // before the fold, ticks folding, items | s_memtime cycles << 16, values.
 template <bool STAMP>
-__global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK)
-k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *band_rep, const u32 *band_beg,
-            const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
+__global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // four wavefronts per SIMD = two workgroups per CU: at most 128 VGPRs (the stamped build took 129 and ran one per CU)
+k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *item_dot, const u32 *band_row0, const u32 *band_rep,
+            const u32 *band_beg, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
             double *partials, unsigned long long *stamps)
 {
     unsigned long long t_start = 0, t_mark = 0, t_zero = 0, t_stream = 0, t_bar = 0, t_fold = 0, n_vals = 0;
@@ -555,16 +555,44 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
     // leaves one record per (round, wavefront) in LDS.  Before, every item began with those two dependent round trips
     // (14 us of a workgroup's 165 on the 10 M-vertex graph, profiles/r3_gather_stamps.txt).
     // record: beg, end, row0, rows, rep, item.w (slot / marker), live (0: this wavefront has nothing to do in a group item)
+    //
+    // Behind the static lists may come a DYNAMIC TAIL (n_dyn > 0: test shape pb_dyn_share; off by default): the cheapest items
+    // (a fixed share of the pass's work, items[n_static .. n_static + n_dyn), dearest first) are not dealt by the host but drawn
+    // from a counter by whichever workgroup has finished its list.  Equal bytes do not take workgroups equal time (the static
+    // schedule ends between 122 and 192 us on the 10 M-vertex graph); the tail evens that out (170 .. 194 us) -- and the pass
+    // ends when it did before, because its bound is the aggregate streaming rate: a workgroup that finishes early leaves its
+    // bandwidth to the others (profiles/r3_gather_balance.txt).  Kept as a measured alternative, exercised by the parity tests.  A drawn item leaves its share of alpha in item_dot[ticket] (closed in ticket
+    // order by k_pb_finish), so alpha does not depend on who drew what.  Every workgroup draws exactly one ticket >= n_dyn
+    // (its exit), so the counter ends at n_dyn + grid: the workgroup that drew the last ticket puts it back to 0 for the
+    // next launch.
     constexpr u32 MAXR = 16;
     u32 *lrec = reinterpret_cast<u32 *>(wsum + WAVES);   // [MAXR][WAVES][8]
-    for (u32 it0 = blockIdx.x; it0 < n_items; it0 += MAXR * gridDim.x) {
-    __syncthreads();                     // the previous batch's records are no longer read
-    for (u32 t = tid; t < MAXR * WAVES; t += LZX_PB_GATHER_BLOCK) {
+    u32 *ltick = lrec + MAXR * WAVES * 8;                // the ticket wavefront 0 drew
+    auto uni = [](u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); };
+    u32 it0 = blockIdx.x;
+    bool dyn = false;
+    for (;;) {
+    if (!dyn && it0 >= n_static) dyn = true;
+    if (dyn && n_dyn == 0) break;
+    __syncthreads();                     // the previous batch's records (and the previous item's tiles) are no longer read
+    u32 base = it0, stride = gridDim.x, limit = n_static, nrounds = MAXR, ticket = 0;
+    if (dyn) {
+        if (tid == 0) *ltick = atomicAdd(counter, 1u);
+        __syncthreads();
+        ticket = uni(*ltick);
+        if (ticket >= n_dyn) {
+            if (tid == 0 && ticket == n_dyn + gridDim.x - 1) *counter = 0u;   // the last draw of this launch
+            break;
+        }
+        base = n_static + ticket; stride = 0; limit = base + 1; nrounds = 1;
+        __syncthreads();                 // everybody has read the ticket before thread 0 may draw the next one
+    }
+    for (u32 t = tid; t < nrounds * WAVES; t += LZX_PB_GATHER_BLOCK) {
         const u32 r = t / WAVES, w = t % WAVES;
-        const u32 it = it0 + r * gridDim.x;
+        const u32 it = base + r * stride;
         u32 *o = lrec + (size_t)t * 8;
         uint4 item = make_uint4(0u, 0u, 0u, LZX_PB_ITEM_NONE);
-        if (it < n_items) item = items[it];
+        if (it < limit) item = items[it];
         o[5] = item.w;
         o[6] = 0u;
         if (item.w == LZX_PB_ITEM_GROUP) {
@@ -580,9 +608,10 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
         }
     }
     __syncthreads();
-    for (u32 rr = 0; rr < MAXR && it0 + rr * gridDim.x < n_items; ++rr) {
+    const double dot_static = dot;       // a drawn item's share of alpha is kept apart (item_dot)
+    if (dyn) dot = 0.0;
+    for (u32 rr = 0; rr < nrounds && base + rr * stride < limit; ++rr) {
         const u32 *rec = lrec + ((size_t)rr * WAVES + wv) * 8;
-        auto uni = [](u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); };
         const u32 r_beg = uni(rec[0]), r_end = uni(rec[1]), r_row0 = uni(rec[2]), r_rows = uni(rec[3]), r_rep = uni(rec[4]);
         const u32 item_w = uni(rec[5]), r_live = uni(rec[6]);
         if (item_w == LZX_PB_ITEM_NONE) continue;   // filler of the balanced schedule
@@ -775,7 +804,21 @@ k_pb_gather(const uint4 *items, u32 n_items, const u32 *band_row0, const u32 *ba
         }
         GSTAMP(t_fold);
     }
-    }   // batches of MAXR rounds
+    if (dyn) {
+        const double idot = wave_sum_pb(dot);
+        dot = dot_static;
+        __syncthreads();                 // wsum free (the single-row path uses it too)
+        if (lane == 0) wsum[wv] = idot;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (u32 w = 0; w < WAVES; ++w) t += wsum[w];
+            item_dot[ticket] = t;
+        }
+    } else {
+        it0 += MAXR * gridDim.x;
+    }
+    }   // batches: up to MAXR static rounds, or one drawn item
     if (STAMP && tid == 0) {
         unsigned long long *o = stamps + 8 * (size_t)blockIdx.x;
         o[0] = t_start; o[1] = wall_clock64(); o[2] = t_zero; o[3] = t_stream; o[4] = t_bar; o[5] = t_fold;
@@ -855,6 +898,7 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_grec);
     pb_free(c->d_pb_item_dot);
     pb_free(c->d_pb_gqueue);
+    pb_free(c->d_pb_gcounter);
     c->pb_g3 = false;
     c->pb_gq_base = 0;
     pb_free(c->d_pb_queue);
@@ -865,7 +909,7 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pbr_base);
     c->pb = false;
     c->pb_entries = c->pb_values = c->pbr_entries = 0;
-    c->pb_units = c->pb_units0 = c->pb_nr = c->pb_gather_grid = c->pb_n_items = c->pb_n_multi = c->pb_finish_grid = 0;
+    c->pb_units = c->pb_units0 = c->pb_nr = c->pb_gather_grid = c->pb_n_items = c->pb_n_static = c->pb_n_dyn = c->pb_n_multi = c->pb_finish_grid = 0;
     c->pbr_steps = 0;
 }
 
@@ -1323,12 +1367,14 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             items.push_back(R); items.push_back(beg); items.push_back(end); items.push_back(0xffffffffu);
         }
     }
-    c->pb_n_items = (u32)(items.size() / 4);
+    c->pb_n_items = c->pb_n_static = (u32)(items.size() / 4);
+    c->pb_n_dyn = 0;
     c->pb_n_multi = (u32)(multi.size() / 4);
     // one item per workgroup at a time, two workgroups per CU
     // 16 wavefronts per CU (their private y tiles fill the LDS): two workgroups of eight, or four of four
     c->pb_gather_block = c->pb_gwaves_opt == 4 ? 256u : 512u;
     c->pb_gather_grid = std::min<u32>((u32)c->cu_count * (1024u / c->pb_gather_block), std::max(1u, c->pb_n_items));
+    if (c->pb_grid_cap_opt > 0) c->pb_gather_grid = std::min<u32>(c->pb_gather_grid, (u32)c->pb_grid_cap_opt);   // test shape: few workgroups, many rounds
     LZX_TRY(pb_alloc(&c->d_pb_beg, (u64)nr + 1));
     LZX_HIP(hipMemcpyAsync(c->d_pb_beg, rstart.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
     const u32 group_cap = c->pb_group_opt >= 0 ? (u32)c->pb_group_opt : LZX_PB_GROUP;
@@ -1394,11 +1440,23 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         std::vector<u32> order(no);
         for (size_t i = 0; i < no; ++i) order[i] = (u32)i;
         std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b2) { return cost[a] > cost[b2]; });
+        // the dynamic tail (k_pb_gather): the cheapest items, `share` per cent of the pass's estimated cost, are drawn from a
+        // counter at run time instead of being dealt here; only when every workgroup has more than one item to its name
+        size_t n_tail = 0;
+        {
+            const u64 share = c->pb_dyn_opt >= 0 ? (u64)std::min<int64_t>(90, c->pb_dyn_opt) : LZX_PB_DYN_SHARE;
+            u64 all = 0, tail = 0;
+            for (u64 x : cost) all += x;
+            if (!g3 && share > 0 && no > (c->pb_dyn_opt > 0 ? 1 : 2) * (size_t)G)
+                while (n_tail + G < no && (tail + cost[order[no - 1 - n_tail]]) * 100 <= all * share) tail += cost[order[no - 1 - n_tail++]];
+        }
+        const size_t n_dealt = no - n_tail;
         std::vector<std::vector<u32>> lists(G);
         std::priority_queue<std::pair<u64, u32>, std::vector<std::pair<u64, u32>>, std::greater<std::pair<u64, u32>>> heap;
         for (u32 w = 0; w < G; ++w) heap.push({0ull, w});
         size_t rounds = 0;
-        for (u32 i : order) {
+        for (size_t oi = 0; oi < n_dealt; ++oi) {
+            const u32 i = order[oi];
             auto [load, w] = heap.top();
             heap.pop();
             lists[w].push_back(i);
@@ -1416,6 +1474,12 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
                     o[3] = LZX_PB_ITEM_NONE;
                 }
             }
+        c->pb_n_static = (u32)(items.size() / 4);
+        for (size_t oi = n_dealt; oi < no; ++oi) {   // the tail behind the static rounds, dearest first
+            const u32 *it = &out[4 * (size_t)order[oi]];
+            items.insert(items.end(), it, it + 4);
+        }
+        c->pb_n_dyn = (u32)n_tail;
         c->pb_n_items = (u32)(items.size() / 4);
     }
 #ifdef LZX_DEBUG_KNOBS
@@ -1444,6 +1508,12 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     if (!multi.empty())
         LZX_HIP(hipMemcpyAsync(c->d_pb_multi, multi.data(), sizeof(u32) * multi.size(), hipMemcpyHostToDevice, st));
 
+    LZX_TRY(pb_alloc(&c->d_pb_gcounter, 4));
+    LZX_HIP(hipMemsetAsync(c->d_pb_gcounter, 0, sizeof(u32) * 4, st));
+    if (c->pb_n_dyn) {
+        LZX_TRY(pb_alloc(&c->d_pb_item_dot, c->pb_n_dyn));
+        LZX_HIP(hipMemsetAsync(c->d_pb_item_dot, 0, sizeof(double) * c->pb_n_dyn, st));
+    }
     LZX_TRY(pb_alloc(&c->d_pb_val, len + 8));
     LZX_HIP(hipMemsetAsync(c->d_pb_val, 0, sizeof(double) * (len + 8), st));
     LZX_HIP(hipStreamSynchronize(st));
@@ -1458,6 +1528,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     (void)waves_per_wg;
     c->pb_finish_grid = (c->pb_n_multi + c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;   // + the split rows of k_spmv
     if (c->pb_g3) c->pb_finish_grid = std::max<u32>(c->pb_finish_grid, (c->pb_g3_items + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK);   // + the gather pass's item partials
+    if (c->pb_n_dyn) c->pb_finish_grid = std::max<u32>(c->pb_finish_grid, (c->pb_n_dyn + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK);   // + the drawn items' alpha partials
     return LZX_OK;
 }
 #undef GRID
@@ -1538,7 +1609,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     }
     if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double) +
-                        16 * (LZX_PB_GATHER_BLOCK / 64) * 8 * sizeof(u32);   // tiles, wavefront sums, the preloaded item records
+                        16 * (LZX_PB_GATHER_BLOCK / 64) * 8 * sizeof(u32) + 16;   // tiles, wavefront sums, the preloaded item records, the ticket
     LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     bool gathered = false;
@@ -1549,8 +1620,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         if (!gathered && c->pb_stamps_opt > 0 && c->d_pb_gstamps) {   // the product kernel with its section stamps
             LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             hipLaunchKernelGGL(k_pb_gather<true>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
-                               reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,
-                               c->d_pb_val, v, q_loc, c->d_pb_part, partials, c->d_pb_gstamps);
+                               reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_static, c->pb_n_dyn, c->d_pb_gcounter, c->d_pb_item_dot, c->d_pb_row0,
+                               c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, c->d_pb_gstamps);
             gathered = true;
         }
     }
@@ -1559,13 +1630,13 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         // experiment: scatter pass alone
     } else if (!gathered)
         hipLaunchKernelGGL(k_pb_gather<false>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
-                           reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_items, c->d_pb_row0, c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow,
-                           c->d_pb_val, v, q_loc, c->d_pb_part, partials, nullptr);
+                           reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_static, c->pb_n_dyn, c->d_pb_gcounter, c->d_pb_item_dot, c->d_pb_row0,
+                           c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, nullptr);
     if (c->pb_finish_grid)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, c->d_item_first,
                            c->d_long_partial, c->d_pb_long_multi, c->n_long64, v, q_loc, partials + (c->pb_g3 ? 0u : c->pb_gather_grid),
-                           c->pb_g3 ? c->d_pb_item_dot : nullptr, c->pb_g3 ? c->pb_g3_items : 0u);
+                           (c->pb_g3 || c->pb_n_dyn) ? c->d_pb_item_dot : nullptr, c->pb_g3 ? c->pb_g3_items : c->pb_n_dyn);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }

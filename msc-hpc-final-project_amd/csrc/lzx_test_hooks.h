@@ -2,6 +2,7 @@
 // Forces the table shapes that large graphs get by themselves onto small test graphs, so that tests/ exercise the product
 // library's own kernels in every shape: "pb_reduce" (minimum run length of a reduced run; 0 = every run plain), "pb_target"
 // (values per gather item), "pb_unit" (entries per scatter unit), "pb_column_band" (8192 | 16384), "pb_run_align", "pb_taper",
+// "pb_dyn_share" (per cent of the gather pass left to its dynamic tail; 0 = every item dealt by the host), "pb_gather_grid" (at most this many gather workgroups),
 // "pb_group" / "pb_group_force" (small row bands gathered one wavefront each), "narrow_slices", "tie_sort", "long_row",
 // "item_len", and "exchange_at_world_1" (a 1-rank RCCL communicator runs the several-rank loop, collectives included).
 #pragma once
@@ -11,3 +12,9 @@
 extern "C"
 #endif
 int lzx_test_set_shape(lzx_handle h, const char *name, int64_t value);
+// what shape the tables of the handle's graph took: "gather_items_dealt" / "gather_items_drawn" (static lists / dynamic tail of
+// the gather pass), "gather_workgroups"
+#ifdef __cplusplus
+extern "C"
+#endif
+int lzx_test_get_shape(lzx_handle h, const char *name, int64_t *value);

@@ -27,7 +27,11 @@ MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propag
          # the forms large graphs get by themselves, forced on small ones: narrow staged-only slices class by class, small row
          # bands gathered one wavefront each (eight per item), rows ranked by staged-column count first
          dict(propagation_blocking=1, hub_entries=64, narrow_slices=1, pb_group_force=8, pb_target=2048),
-         dict(propagation_blocking=1, hub_entries=256, narrow_slices=1, pb_group_force=8, pb_group=1024, tie_sort=2)]
+         dict(propagation_blocking=1, hub_entries=256, narrow_slices=1, pb_group_force=8, pb_group=1024, tie_sort=2),
+         # the gather pass's dynamic tail (large graphs: the cheapest fifth of the items is drawn from a counter by whichever
+         # workgroup has finished its list): few workgroups, many small items, 40 % of them drawn; and with grouped bands
+         dict(propagation_blocking=1, hub_entries=64, pb_target=1024, pb_gather_grid=8, pb_dyn_share=40),
+         dict(propagation_blocking=1, hub_entries=64, pb_target=2048, pb_group_force=4, pb_gather_grid=6, pb_dyn_share=60)]
 
 
 def graphs(O):
@@ -123,6 +127,9 @@ def test_spmv_matches_oracle(oracle, engine_factory):
             if mode.get("pb_reduce", 1) == 0:      # one value per (padded) entry
                 assert gi["pb_reduced_entries"] == 0 and gi["pb_values"] >= gi["pb_entries"], (name, mode)
             assert np.allclose(eng.spmv(x), y_ref, rtol=1e-13, atol=0), (name, mode)
+            if "pb_dyn_share" in mode and name in ("er_200k", "rmat_hub"):   # the tail really is drawn at run time there
+                assert eng.shape("gather_items_drawn") > 0 and eng.shape("gather_workgroups") == mode["pb_gather_grid"], (name, mode)
+                assert np.array_equal(eng.spmv(x), eng.spmv(x)), (name, mode)
             eng.close()
         eng = engine_factory(**MODES[0])
         eng.set_graph_csr(rp, ci)
