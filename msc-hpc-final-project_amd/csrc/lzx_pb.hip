@@ -531,6 +531,30 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
 // STAMP (debug library, option pb_stamps): wavefront 0 of every workgroup keeps 100 MHz time stamps per section --
 // stamps[8 * workgroup ..]: start, end, ticks zeroing tiles + reading item records, ticks streaming, ticks in barriers
 // before the fold, ticks folding, items | s_memtime cycles << 16, values.
+// the gather pass's stream loads: every value and slot is read exactly once.  LZX_GATHER_NT (build-time experiment): as
+// non-temporal loads
+#ifndef LZX_GATHER_NT
+#define LZX_GATHER_NT 0
+#endif
+__device__ __forceinline__ double2 gld_val2(const double *p)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+#if LZX_GATHER_NT
+    const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+#else
+    const d2v t = *reinterpret_cast<const d2v *>(p);
+#endif
+    return make_double2(t.x, t.y);
+}
+__device__ __forceinline__ u32 gld_slot2(const uint16_t *p)
+{
+#if LZX_GATHER_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const u32 *>(p));
+#else
+    return *reinterpret_cast<const u32 *>(p);
+#endif
+}
+
 template <bool STAMP>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // four wavefronts per SIMD = two workgroups per CU: at most 128 VGPRs (the stamped build took 129 and ran one per CU)
 k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *item_dot, const u32 *band_row0, const u32 *band_rep,
@@ -636,8 +660,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const u32 p = beg + (kb + u) * 128u + lane * 2;
-                        av[u] = *reinterpret_cast<const double2 *>(val + p);
-                        sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                        av[u] = gld_val2(val + p);
+                        sv[u] = gld_slot2(lslot + p);
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -654,8 +678,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     for (int u = 0; u < 7; ++u) {
                         if (kb + u < blocks) {           // wave-uniform
                             const u32 p = beg + (kb + u) * 128u + lane * 2;
-                            av[u] = *reinterpret_cast<const double2 *>(val + p);
-                            sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                            av[u] = gld_val2(val + p);
+                            sv[u] = gld_slot2(lslot + p);
                         }
                     }
 #pragma unroll
@@ -750,8 +774,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const u32 p = beg + (kb + u * WAVES) * 128u + lane * 2;
-                av[u] = *reinterpret_cast<const double2 *>(val + p);
-                sv[u] = *reinterpret_cast<const u32 *>(lslot + p);
+                av[u] = gld_val2(val + p);
+                sv[u] = gld_slot2(lslot + p);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -761,8 +785,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
         }
         for (; kb < blocks; kb += WAVES) {
             const u32 p = beg + kb * 128u + lane * 2;
-            const double2 a = *reinterpret_cast<const double2 *>(val + p);
-            const u32 s = *reinterpret_cast<const u32 *>(lslot + p);
+            const double2 a = gld_val2(val + p);
+            const u32 s = gld_slot2(lslot + p);
             atomicAdd(&ytile[s & 0xffffu], a.x);
             atomicAdd(&ytile[s >> 16], a.y);
         }

@@ -44,6 +44,19 @@ def test_c2_full_size(pkg, oracle):
     rp, ci = eng.get_graph_csr()
     st = check_properties(eng, gi["n"], 8, np.random.default_rng(2), spmv_ref=lambda x: O.spmv(rp, ci, x))
     assert st["spmv_bytes"] == 4 * gi["nnz"] + 4 * (gi["n"] + 1) + 16 * gi["n"]
+    # the same graph with the gather pass's dynamic tail at work (64 workgroups, a third of the pass drawn at run time):
+    # the same numbers as the static schedule to rounding, and its own bits run after run
+    dyn = pkg.Engine(0, pb_gather_grid=64, pb_dyn_share=33)
+    dyn.set_graph_csr(rp, ci)
+    assert dyn.shape("gather_items_drawn") > 0 and dyn.shape("gather_workgroups") == 64
+    x = np.random.default_rng(3).random(gi["n"])
+    y_dyn = dyn.spmv(x)
+    assert np.allclose(y_dyn, O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+    assert np.array_equal(y_dyn, dyn.spmv(x))
+    a1, b1, _, _, _ = dyn.lanczos(np.ones(gi["n"]), 12, want_q=False)
+    a2, b2, _, _, _ = dyn.lanczos(np.ones(gi["n"]), 12, want_q=False)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+    dyn.close()
     eng.close()
 
 
