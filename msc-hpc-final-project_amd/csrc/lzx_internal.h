@@ -58,6 +58,7 @@ static constexpr u32 LZX_PB_TARGET = 32768;   // upper limit of the values per g
 static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
 static constexpr u32 LZX_PB_GROUP = 16384;    // a row band of at most this many values is gathered by one wavefront (k_pb_gather)
+static constexpr unsigned long long LZX_PB_NT_BYTES = 128ull << 20;   // a gather value stream (values + slots) above this is read with non-temporal loads
 static constexpr u32 LZX_PB_DYN_SHARE = 0;    // per cent of the gather pass's estimated cost whose items are drawn at run time (k_pb_gather's dynamic tail): off --
                                                // it evens the workgroups' end times out (170-194 us instead of 122-192 on the 10 M-vertex graph) and the pass ends when it did
                                                // before: its bound is the aggregate streaming rate, early finishers only leave their bandwidth to the others (DESIGN 3.1 j)
@@ -233,6 +234,7 @@ struct lzx_ctx {
     u32 *d_pb_gqueue = nullptr;        // the ticket counter (never reset)
     u32 pb_n_static = 0, pb_n_dyn = 0; // gather items dealt to workgroups by the host / drawn from d_pb_gcounter at run time (k_pb_gather)
     u32 *d_pb_gcounter = nullptr;      // the dynamic tail's ticket counter (back to 0 at the end of every launch)
+    int64_t pb_gather_nt_opt = -1;     // test shape pb_gather_nt: the gather pass's stream loads non-temporal (1) or cached (0); -1: by the stream's size
     int64_t pb_grid_cap_opt = -1;      // test shape pb_gather_grid: at most this many gather workgroups
     int64_t pb_dyn_opt = -1;           // test shape pb_dyn_share: per cent of the gather pass's cost left to the dynamic tail (-1: default)
     u32 pb_gq_base = 0;                // its value when the next launch starts

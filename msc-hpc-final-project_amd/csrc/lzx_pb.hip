@@ -339,6 +339,65 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 //   plain part: each wavefront walks its own contiguous share of the quads 64 at a time (lane = consecutive quad):
 //       contiguous loads, and 32-byte-per-lane stores that are contiguous inside a run; 4 quads per lane in flight.
 // (The LZX_ABLATE switches behind DESIGN.md's ablation numbers live in a copy of this body in lzx_pb_dbg.hip.)
+// build-time experiments on the scatter pass's cache policy: LZX_NT_SCODE -- its tables (codes, quad columns and slots: read
+// once per SpMV) as non-temporal loads; LZX_NT_SVAL -- its value stores as non-temporal stores
+#ifndef LZX_NT_SCODE
+#define LZX_NT_SCODE 0
+#endif
+#ifndef LZX_NT_SVAL
+#define LZX_NT_SVAL 0
+#endif
+#ifndef LZX_NT_STAGED
+#define LZX_NT_STAGED 0
+#endif
+__device__ __forceinline__ u32 sld_u32(const u32 *p)
+{
+#if LZX_NT_SCODE
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint4 sld_u4(const uint4 *p)
+{
+#if LZX_NT_SCODE
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint2 sld_u2(const uint2 *p)
+{
+#if LZX_NT_SCODE
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const u2v t = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(p));
+    return make_uint2(t.x, t.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void sst_f64(double *p, double v)
+{
+#if LZX_NT_SVAL
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void sst_f64x2(double2 *p, const double2 &v)
+{
+#if LZX_NT_SVAL
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v t;
+    t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<d2v *>(p));
+#else
+    *p = v;
+#endif
+}
+
 template <u32 CB>
 __device__ __forceinline__ void
 pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
@@ -403,7 +462,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                 const unsigned long long m = __ballot(f);
                 if (m) {               // scalar branch: steps of few long rows have mostly empty planes
                     if (f) {
-                        out[done + lanes_below(m)] = s;
+                        sst_f64(out + done + lanes_below(m), s);
                         s = 0.0;
                     }
                     done += (u32)__popcll(m);
@@ -416,7 +475,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
             u32 b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                c[u] = sld_u4(scode + (size_t)(s + u * W) * 64 + lane);
                 b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
             }
 #pragma unroll
@@ -428,7 +487,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 if (s + u * W < end) {
-                    c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                    c[u] = sld_u4(scode + (size_t)(s + u * W) * 64 + lane);
                     b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
                 }
             }
@@ -450,8 +509,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
             u32 d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                c[u] = q_lcol[j + u * 64];
-                d[u] = q_dst[j + u * 64];
+                c[u] = sld_u2(q_lcol + j + u * 64);
+                d[u] = sld_u32(q_dst + j + u * 64);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -461,8 +520,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                 hi.x = tile[c[u].y & 0xffffu];
                 hi.y = tile[c[u].y >> 16];
                 double2 *out = reinterpret_cast<double2 *>(val + d[u]);   // 32-byte aligned: slots of a quad
-                out[0] = lo;
-                out[1] = hi;
+                sst_f64x2(out, lo);
+                sst_f64x2(out + 1, hi);
             }
         }
         if (wend < blk + 256u) {   // a partly filled block: up to three more quads per lane, requested together
@@ -471,8 +530,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const u32 jj = j + u * 64 < wend ? j + u * 64 : blk;     // clamped: unconditional loads
-                c[u] = q_lcol[jj];
-                d[u] = q_dst[jj];
+                c[u] = sld_u2(q_lcol + jj);
+                d[u] = sld_u32(q_dst + jj);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -483,8 +542,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                     hi.x = tile[c[u].y & 0xffffu];
                     hi.y = tile[c[u].y >> 16];
                     double2 *out = reinterpret_cast<double2 *>(val + d[u]);
-                    out[0] = lo;
-                    out[1] = hi;
+                    sst_f64x2(out, lo);
+                    sst_f64x2(out + 1, hi);
                 }
             }
         }
@@ -519,7 +578,7 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
         return;
     }
     if (blockIdx.x < n_units) pb_scatter_body<CB>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
-    else spmv_body<2, false>(a, blockIdx.x - n_units, spmv_blocks);
+    else spmv_body<2, LZX_NT_STAGED != 0>(a, blockIdx.x - n_units, spmv_blocks);
 }
 
 // item table entry: {row band, begin, end, slot} in gather positions; slot == 0xffffffff: the item is its band's
@@ -531,31 +590,25 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
 // STAMP (debug library, option pb_stamps): wavefront 0 of every workgroup keeps 100 MHz time stamps per section --
 // stamps[8 * workgroup ..]: start, end, ticks zeroing tiles + reading item records, ticks streaming, ticks in barriers
 // before the fold, ticks folding, items | s_memtime cycles << 16, values.
-// the gather pass's stream loads: every value and slot is read exactly once.  LZX_GATHER_NT (build-time experiment): as
-// non-temporal loads
-#ifndef LZX_GATHER_NT
-#define LZX_GATHER_NT 0
-#endif
+// the gather pass's stream loads: every value and slot is read exactly once.  NT: as non-temporal loads -- they do not
+// displace what the scatter pass has just written from the Infinity Cache, so part of the value stream is read back from
+// there instead of from HBM (10 M-vertex graph: SpMV 0.630 -> 0.575 ms, six of six alternating processes,
+// profiles/r3_nt_ab.txt); chosen by the size of the stream (lzx_pb_launch): a stream that fits the caches whole (1 M-vertex
+// graph, 33 MB) is read 5 % faster through them.
+template <bool NT>
 __device__ __forceinline__ double2 gld_val2(const double *p)
 {
     typedef double d2v __attribute__((ext_vector_type(2)));
-#if LZX_GATHER_NT
-    const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
-#else
-    const d2v t = *reinterpret_cast<const d2v *>(p);
-#endif
+    const d2v t = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p)) : *reinterpret_cast<const d2v *>(p);
     return make_double2(t.x, t.y);
 }
+template <bool NT>
 __device__ __forceinline__ u32 gld_slot2(const uint16_t *p)
 {
-#if LZX_GATHER_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const u32 *>(p));
-#else
-    return *reinterpret_cast<const u32 *>(p);
-#endif
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const u32 *>(p)) : *reinterpret_cast<const u32 *>(p);
 }
 
-template <bool STAMP>
+template <bool STAMP, bool NT>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // four wavefronts per SIMD = two workgroups per CU: at most 128 VGPRs (the stamped build took 129 and ran one per CU)
 k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *item_dot, const u32 *band_row0, const u32 *band_rep,
             const u32 *band_beg, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
@@ -660,8 +713,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const u32 p = beg + (kb + u) * 128u + lane * 2;
-                        av[u] = gld_val2(val + p);
-                        sv[u] = gld_slot2(lslot + p);
+                        av[u] = gld_val2<NT>(val + p);
+                        sv[u] = gld_slot2<NT>(lslot + p);
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -678,8 +731,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     for (int u = 0; u < 7; ++u) {
                         if (kb + u < blocks) {           // wave-uniform
                             const u32 p = beg + (kb + u) * 128u + lane * 2;
-                            av[u] = gld_val2(val + p);
-                            sv[u] = gld_slot2(lslot + p);
+                            av[u] = gld_val2<NT>(val + p);
+                            sv[u] = gld_slot2<NT>(lslot + p);
                         }
                     }
 #pragma unroll
@@ -774,8 +827,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const u32 p = beg + (kb + u * WAVES) * 128u + lane * 2;
-                av[u] = gld_val2(val + p);
-                sv[u] = gld_slot2(lslot + p);
+                av[u] = gld_val2<NT>(val + p);
+                sv[u] = gld_slot2<NT>(lslot + p);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -785,8 +838,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
         }
         for (; kb < blocks; kb += WAVES) {
             const u32 p = beg + kb * 128u + lane * 2;
-            const double2 a = gld_val2(val + p);
-            const u32 s = gld_slot2(lslot + p);
+            const double2 a = gld_val2<NT>(val + p);
+            const u32 s = gld_slot2<NT>(lslot + p);
             atomicAdd(&ytile[s & 0xffffu], a.x);
             atomicAdd(&ytile[s >> 16], a.y);
         }
@@ -1634,18 +1687,22 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into
     const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double) +
                         16 * (LZX_PB_GATHER_BLOCK / 64) * 8 * sizeof(u32) + 16;   // tiles, wavefront sums, the preloaded item records, the ticket
-    LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    // stream loads of the pass as non-temporal loads when the value stream is larger than the caches can hold anyway (k_pb_gather)
+    const bool nt = c->pb_gather_nt_opt >= 0 ? c->pb_gather_nt_opt > 0 : 10ull * c->pb_values > LZX_PB_NT_BYTES;
+    auto gather = [&](auto kern, unsigned long long *stamps) -> int {
+        LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(kern, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
+                           reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_static, c->pb_n_dyn, c->d_pb_gcounter, c->d_pb_item_dot, c->d_pb_row0,
+                           c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, stamps);
+        return LZX_OK;
+    };
     bool gathered = false;
 #ifdef LZX_DEBUG_KNOBS
     if (!(c->phase_mask_opt & 8)) {
         gathered = lzx_pbdbg_gather(c, v, q_loc, partials, &dbg_rc);   // persistent / ticketed experiments
         LZX_TRY(dbg_rc);
         if (!gathered && c->pb_stamps_opt > 0 && c->d_pb_gstamps) {   // the product kernel with its section stamps
-            LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pb_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            hipLaunchKernelGGL(k_pb_gather<true>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
-                               reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_static, c->pb_n_dyn, c->d_pb_gcounter, c->d_pb_item_dot, c->d_pb_row0,
-                               c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, c->d_pb_gstamps);
+            LZX_TRY(nt ? gather(k_pb_gather<true, true>, c->d_pb_gstamps) : gather(k_pb_gather<true, false>, c->d_pb_gstamps));
             gathered = true;
         }
     }
@@ -1653,9 +1710,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     if (c->phase_mask_opt & 8) {
         // experiment: scatter pass alone
     } else if (!gathered)
-        hipLaunchKernelGGL(k_pb_gather<false>, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
-                           reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_static, c->pb_n_dyn, c->d_pb_gcounter, c->d_pb_item_dot, c->d_pb_row0,
-                           c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, nullptr);
+        LZX_TRY(nt ? gather(k_pb_gather<false, true>, nullptr) : gather(k_pb_gather<false, false>, nullptr));
     if (c->pb_finish_grid)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, c->d_item_first,

@@ -3,6 +3,7 @@
 // library's own kernels in every shape: "pb_reduce" (minimum run length of a reduced run; 0 = every run plain), "pb_target"
 // (values per gather item), "pb_unit" (entries per scatter unit), "pb_column_band" (8192 | 16384), "pb_run_align", "pb_taper",
 // "pb_dyn_share" (per cent of the gather pass left to its dynamic tail; 0 = every item dealt by the host), "pb_gather_grid" (at most this many gather workgroups),
+// "pb_gather_nt" (the gather pass's stream loads non-temporal 1 / cached 0, whatever the stream's size),
 // "pb_group" / "pb_group_force" (small row bands gathered one wavefront each), "narrow_slices", "tie_sort", "long_row",
 // "item_len", and "exchange_at_world_1" (a 1-rank RCCL communicator runs the several-rank loop, collectives included).
 #pragma once
