@@ -128,18 +128,6 @@ k_axpy_norm(double *v, const double *__restrict__ qj, const double *__restrict__
 //   u_{j+1} = A q_j - alpha_j q_j - beta_{j-1} q_{j-1}   (serial/lib/lanczos.cc:26-37, same two rounded updates)
 // first: u_0 = q_0 is already normalised (B := 1).  u_next == nullptr on the last iteration (only q_j is still needed).
 // scal2 == nullptr (one rank): D and B are the fixed-order sums of pa[0..na) and pb[0..nb), closed here by every workgroup.
-// build-time experiment on the vector kernel's cache policy: LZX_VEC_NT bit 0 -- w = A u_j (never read again), bit 1 -- u_{j-1}
-// (never read again), bit 2 -- u_j (read once more, one iteration later) as non-temporal loads
-#ifndef LZX_VEC_NT
-#define LZX_VEC_NT 0
-#endif
-template <int NT>
-__device__ __forceinline__ double2 vld2(const double *p)
-{
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    const d2v t = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p)) : *reinterpret_cast<const d2v *>(p);
-    return make_double2(t.x, t.y);
-}
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict__ u, const double *__restrict__ q_prev,
               const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
@@ -187,7 +175,7 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
     const double bprev = prev_div ? *prev_div : 1.0;
     if (!q_out && !u_next) n = 0;   // last iteration with the unnormalised basis: only the scalars were wanted
     for (u32 i = (blockIdx.x * LZX_VEC_BLOCK + threadIdx.x) * 2; i < n; i += stride) {
-        double2 q = vld2<(LZX_VEC_NT >> 2) & 1>(u + i);
+        double2 q = *reinterpret_cast<const double2 *>(u + i);
         if (!first) {
             q.x /= beta;
             q.y /= beta;
@@ -195,7 +183,7 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
         if (q_out) *reinterpret_cast<double2 *>(q_out + i) = q;
         if (u_next) {
             // rows without an edge (the tail beyond w_rows) have (A u)_i = 0: not read, and the SpMV did not write them
-            double2 t = i < w_rows ? vld2<LZX_VEC_NT & 1>(w + i) : make_double2(0.0, 0.0);
+            double2 t = i < w_rows ? *reinterpret_cast<const double2 *>(w + i) : make_double2(0.0, 0.0);
             if (!first) {
                 t.x /= beta;
                 t.y /= beta;
@@ -203,7 +191,7 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
             t.x -= alpha * q.x;
             t.y -= alpha * q.y;
             if (q_prev) {
-                double2 p = vld2<(LZX_VEC_NT >> 1) & 1>(q_prev + i);
+                double2 p = *reinterpret_cast<const double2 *>(q_prev + i);
                 if (prev_div) {   // the column holds u_{j-1}: q_{j-1} = u_{j-1} / beta_{j-2}, as it was formed one iteration ago
                     p.x /= bprev;
                     p.y /= bprev;

@@ -339,65 +339,6 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 //   plain part: each wavefront walks its own contiguous share of the quads 64 at a time (lane = consecutive quad):
 //       contiguous loads, and 32-byte-per-lane stores that are contiguous inside a run; 4 quads per lane in flight.
 // (The LZX_ABLATE switches behind DESIGN.md's ablation numbers live in a copy of this body in lzx_pb_dbg.hip.)
-// build-time experiments on the scatter pass's cache policy: LZX_NT_SCODE -- its tables (codes, quad columns and slots: read
-// once per SpMV) as non-temporal loads; LZX_NT_SVAL -- its value stores as non-temporal stores
-#ifndef LZX_NT_SCODE
-#define LZX_NT_SCODE 0
-#endif
-#ifndef LZX_NT_SVAL
-#define LZX_NT_SVAL 0
-#endif
-#ifndef LZX_NT_STAGED
-#define LZX_NT_STAGED 0
-#endif
-__device__ __forceinline__ u32 sld_u32(const u32 *p)
-{
-#if LZX_NT_SCODE
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ uint4 sld_u4(const uint4 *p)
-{
-#if LZX_NT_SCODE
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
-    return make_uint4(t.x, t.y, t.z, t.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ uint2 sld_u2(const uint2 *p)
-{
-#if LZX_NT_SCODE
-    typedef unsigned u2v __attribute__((ext_vector_type(2)));
-    const u2v t = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(p));
-    return make_uint2(t.x, t.y);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void sst_f64(double *p, double v)
-{
-#if LZX_NT_SVAL
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ void sst_f64x2(double2 *p, const double2 &v)
-{
-#if LZX_NT_SVAL
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    d2v t;
-    t.x = v.x; t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<d2v *>(p));
-#else
-    *p = v;
-#endif
-}
-
 template <u32 CB>
 __device__ __forceinline__ void
 pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
@@ -462,7 +403,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                 const unsigned long long m = __ballot(f);
                 if (m) {               // scalar branch: steps of few long rows have mostly empty planes
                     if (f) {
-                        sst_f64(out + done + lanes_below(m), s);
+                        out[done + lanes_below(m)] = s;
                         s = 0.0;
                     }
                     done += (u32)__popcll(m);
@@ -475,7 +416,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
             u32 b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                c[u] = sld_u4(scode + (size_t)(s + u * W) * 64 + lane);
+                c[u] = scode[(size_t)(s + u * W) * 64 + lane];
                 b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
             }
 #pragma unroll
@@ -487,7 +428,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 if (s + u * W < end) {
-                    c[u] = sld_u4(scode + (size_t)(s + u * W) * 64 + lane);
+                    c[u] = scode[(size_t)(s + u * W) * 64 + lane];
                     b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
                 }
             }
@@ -509,8 +450,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
             u32 d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                c[u] = sld_u2(q_lcol + j + u * 64);
-                d[u] = sld_u32(q_dst + j + u * 64);
+                c[u] = q_lcol[j + u * 64];
+                d[u] = q_dst[j + u * 64];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -520,8 +461,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                 hi.x = tile[c[u].y & 0xffffu];
                 hi.y = tile[c[u].y >> 16];
                 double2 *out = reinterpret_cast<double2 *>(val + d[u]);   // 32-byte aligned: slots of a quad
-                sst_f64x2(out, lo);
-                sst_f64x2(out + 1, hi);
+                out[0] = lo;
+                out[1] = hi;
             }
         }
         if (wend < blk + 256u) {   // a partly filled block: up to three more quads per lane, requested together
@@ -530,8 +471,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const u32 jj = j + u * 64 < wend ? j + u * 64 : blk;     // clamped: unconditional loads
-                c[u] = sld_u2(q_lcol + jj);
-                d[u] = sld_u32(q_dst + jj);
+                c[u] = q_lcol[jj];
+                d[u] = q_dst[jj];
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -542,8 +483,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                     hi.x = tile[c[u].y & 0xffffu];
                     hi.y = tile[c[u].y >> 16];
                     double2 *out = reinterpret_cast<double2 *>(val + d[u]);
-                    sst_f64x2(out, lo);
-                    sst_f64x2(out + 1, hi);
+                    out[0] = lo;
+                    out[1] = hi;
                 }
             }
         }
@@ -578,7 +519,7 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
         return;
     }
     if (blockIdx.x < n_units) pb_scatter_body<CB>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
-    else spmv_body<2, LZX_NT_STAGED != 0>(a, blockIdx.x - n_units, spmv_blocks);
+    else spmv_body<2, false>(a, blockIdx.x - n_units, spmv_blocks);
 }
 
 // item table entry: {row band, begin, end, slot} in gather positions; slot == 0xffffffff: the item is its band's
