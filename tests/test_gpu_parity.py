@@ -31,7 +31,9 @@ MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propag
          # the gather pass's dynamic tail (large graphs: the cheapest fifth of the items is drawn from a counter by whichever
          # workgroup has finished its list): few workgroups, many small items, 40 % of them drawn; and with grouped bands
          dict(propagation_blocking=1, hub_entries=64, pb_target=1024, pb_gather_grid=8, pb_dyn_share=40),
-         dict(propagation_blocking=1, hub_entries=64, pb_target=2048, pb_group_force=4, pb_gather_grid=6, pb_dyn_share=60)]
+         # ... and the kernel large graphs get: stream loads non-temporal (chosen by the stream's size; forced here)
+         dict(propagation_blocking=1, hub_entries=64, pb_target=2048, pb_group_force=4, pb_gather_grid=6, pb_dyn_share=60, pb_gather_nt=1),
+         dict(propagation_blocking=1, pb_gather_nt=1)]
 
 
 def graphs(O):
