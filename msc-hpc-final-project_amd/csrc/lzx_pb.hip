@@ -1078,10 +1078,10 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     // the tail.  About four units per CU, between 64 Ki and 128 Ki entries (measured, tools/perf_probe.py @unit and
     // tools/rank_probe.py: C3 on one GPU 128 Ki 0.317 vs 64 Ki 0.344 vs 256 Ki 0.326 ms; its 1/8 share: 32 Ki 0.1055,
     // 64 Ki 0.109, 128 Ki 0.110 ms -- one round of big units leaves the launch as long as its slowest unit);
-    // down to 8 Ki only to give every CU about four units on graphs whose x sits in the L2s anyway
+    // down to 8 Ki only to give every CU about two units (of tapered size) on graphs whose x sits in the L2s anyway
     u32 unit_cap = (u32)std::min<u64>(131072, std::max<u64>(32768, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
     if (c->xlen * sizeof(double) <= (16u << 20))
-        unit_cap = (u32)std::min<u64>(65536, std::max<u64>(8192, (total / ((u64)c->cu_count * 4) + 511) & ~511ull));
+        unit_cap = (u32)std::min<u64>(65536, std::max<u64>(8192, (total / ((u64)c->cu_count * 2) + 511) & ~511ull));   // (1 M-vertex graph: 32 Ki 0.0650, 16 Ki 0.0680, 48 Ki 0.0675, 64 Ki 0.0735 ms per SpMV)
     if (c->pb_unit_opt > 0) unit_cap = (u32)c->pb_unit_opt;
 
     // ---- row bands: consecutive local rows (they are in descending degree order): as many rows as the wave-private
