@@ -136,7 +136,11 @@ extern "C" int lzx_comm_init_local(lzx_handle *hs, int world)
                 ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
                 if (!ok) (void)hipGetLastError();
             }
-            if (!ok) c->mail_ok = false;   // its kernels cannot store into that peer's mailbox
+            // Mailboxes only among handles of ONE device: a peer GPU's kernel stores reach this GPU's memory past its L2, and
+            // nothing tested here says a line of the mailbox this GPU's L2 still holds from two iterations ago is dropped in
+            // time (no box with two GPUs was available in any round).  Across devices the pair travels by copies, as before.
+            (void)ok;
+            c->mail_ok = false;
         }
     }
     // the mailboxes of the two-double reduction (lzx_internal.h: d_mail); without them the group reduces through copies
