@@ -579,10 +579,10 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
     // from a counter by whichever workgroup has finished its list.  Equal bytes do not take workgroups equal time (the static
     // schedule ends between 122 and 192 us on the 10 M-vertex graph); the tail evens that out (170 .. 194 us) -- and the pass
     // ends when it did before, because its bound is the aggregate streaming rate: a workgroup that finishes early leaves its
-    // bandwidth to the others (profiles/r3_gather_balance.txt).  Kept as a measured alternative, exercised by the parity tests.  A drawn item leaves its share of alpha in item_dot[ticket] (closed in ticket
-    // order by k_pb_finish), so alpha does not depend on who drew what.  Every workgroup draws exactly one ticket >= n_dyn
-    // (its exit), so the counter ends at n_dyn + grid: the workgroup that drew the last ticket puts it back to 0 for the
-    // next launch.
+    // bandwidth to the others (profiles/r3_gather_balance.txt).  Kept as a measured alternative, exercised by the parity tests.
+    // A drawn item leaves its share of alpha in item_dot[ticket] (closed in ticket order by k_pb_finish), so alpha does not
+    // depend on who drew what.  Every workgroup draws exactly one ticket >= n_dyn (its exit), so the counter ends at
+    // n_dyn + grid: the workgroup that drew the last ticket puts it back to 0 for the next launch.
     constexpr u32 MAXR = 16;
     u32 *lrec = reinterpret_cast<u32 *>(wsum + WAVES);   // [MAXR][WAVES][8]
     u32 *ltick = lrec + MAXR * WAVES * 8;                // the ticket wavefront 0 drew
