@@ -534,6 +534,8 @@ def test_odd_shapes_through_the_large_graph_forms(oracle, pkg):
     n = 9000
     shapes["skewed, 9 000 vertices"] = O.gen_rmat(14, n, 150000, 3, a=0.65, b=0.15, c=0.15)
     modes = (dict(propagation_blocking=1, hub_entries=64, narrow_slices=1, pb_group_force=8, pb_target=2048),
+             # the gather pass as large graphs get it (non-temporal stream loads) with a dynamic tail over three workgroups
+             dict(propagation_blocking=1, hub_entries=64, narrow_slices=1, pb_target=1024, pb_gather_nt=1, pb_gather_grid=3, pb_dyn_share=50),
              dict(propagation_blocking=1, hub_entries=16384, narrow_slices=1, pb_group_force=2),
              dict(propagation_blocking=1, hub_entries=32, fuse_staged=1, tie_sort=2),
              dict(propagation_blocking=1, hub_entries=32, fuse_staged=0, unnormalised_basis=0))
