@@ -126,6 +126,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_dyn_share")) c->pb_dyn_opt = value;
     else if (!strcmp(name, "pb_gather_grid")) c->pb_grid_cap_opt = value;
     else if (!strcmp(name, "pb_gather_nt")) c->pb_gather_nt_opt = value;
+    else if (!strcmp(name, "spmv_wgs")) c->spmv_wgs_opt = value;
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
     else if (!strcmp(name, "pb_persistent")) c->pb_persist_opt = value;
@@ -169,6 +170,7 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_dyn_share")) c->pb_dyn_opt = value;
     else if (!strcmp(name, "pb_gather_grid")) c->pb_grid_cap_opt = value;
     else if (!strcmp(name, "pb_gather_nt")) c->pb_gather_nt_opt = value;
+    else if (!strcmp(name, "spmv_wgs")) c->spmv_wgs_opt = value;
     else if (!strcmp(name, "pb_group")) c->pb_group_opt = value;
     else if (!strcmp(name, "pb_group_force")) c->pb_group_force_opt = value;
     else if (!strcmp(name, "narrow_slices")) c->narrow_opt = value;

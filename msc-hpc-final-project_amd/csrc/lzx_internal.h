@@ -234,6 +234,7 @@ struct lzx_ctx {
     u32 *d_pb_gqueue = nullptr;        // the ticket counter (never reset)
     u32 pb_n_static = 0, pb_n_dyn = 0; // gather items dealt to workgroups by the host / drawn from d_pb_gcounter at run time (k_pb_gather)
     u32 *d_pb_gcounter = nullptr;      // the dynamic tail's ticket counter (back to 0 at the end of every launch)
+    int64_t spmv_wgs_opt = -1;         // test shape spmv_wgs: at most this many workgroups of k_spmv / staged-columns workgroups of the shared launch
     int64_t pb_gather_nt_opt = -1;     // test shape pb_gather_nt: the gather pass's stream loads non-temporal (1) or cached (0); -1: by the stream's size
     int64_t pb_grid_cap_opt = -1;      // test shape pb_gather_grid: at most this many gather workgroups
     int64_t pb_dyn_opt = -1;           // test shape pb_dyn_share: per cent of the gather pass's cost left to the dynamic tail (-1: default)
