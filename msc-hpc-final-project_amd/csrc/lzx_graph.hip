@@ -756,11 +756,11 @@ int lzx_graph_prepare(lzx_ctx *c)
     const u32 waves_per_wg = LZX_SPMV_BLOCK / 64;
     u32 grid = (u32)c->cu_count * per_cu;
     grid = std::min(grid, std::max(1u, (units + waves_per_wg - 1) / waves_per_wg));
-    // Blocked mode, little staged-columns work per workgroup (below 256 slices + items each: 1 M-vertex graphs, rank shares from
-    // P = 4): half as many, twice as long.  They share the scatter pass's launch; the CUs they leave free start on scatter units
+    // Blocked mode, little staged-columns work per workgroup (below 512 slices + items each: graphs up to a few million vertices,
+    // rank shares from P = 2): half as many, twice as long.  They share the scatter pass's launch; the CUs they leave free start on scatter units
     // at once, and 128 KiB of staged x are fetched half as often (1 M-vertex graph: SpMV 0.0652 -> 0.0595 ms; rank 0 of 8 / of 4:
-    // 0.109 -> 0.100, 0.179 -> 0.173 ms; neutral from 350 slices per workgroup up -- profiles/r3_small_units.txt)
-    if (pb && units < (u32)c->cu_count * 256u) grid = std::min(grid, std::max(1u, (u32)c->cu_count / 2));
+    // 0.109 -> 0.100, 0.179 -> 0.173 ms; 4 M vertices and rank 0 of 2: - 2 %; neutral on the 10 M-vertex graph -- profiles/r3_small_units.txt)
+    if (pb && units < (u32)c->cu_count * 512u) grid = std::min(grid, std::max(1u, (u32)c->cu_count / 2));
     if (c->spmv_wgs_opt > 0) grid = std::min<u32>((u32)c->cu_count * per_cu, std::min<u32>(std::max(1u, (units + waves_per_wg - 1) / waves_per_wg), (u32)c->spmv_wgs_opt));   // test shape spmv_wgs
     c->spmv_grid = grid;
     c->fin_grid = (c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
