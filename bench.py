@@ -4,8 +4,11 @@
     python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|er|er1m|c5]
 
 A "step" is one Lanczos iteration (serial/lib/lanczos.cc:21-53) on a graph already reshaped and resident in
-HBM; the timed region is exactly K iterations (lzx_lanczos_run), bracketed by a barrier and a device
-synchronisation on both sides, MAX over ranks.  N > 1: one process per GPU (torch.distributed.run), rows
+HBM.  The decomposition that is timed is BASELINE's: k = the workload's Krylov dimension (50; C5 30; C1 20 -- what
+parallel-final/main.cu:104-116 times), prepared with lzx_lanczos_prepare_f64(x0, k); the timed region is exactly K = --steps
+iterations of it (lzx_lanczos_run_steps), bracketed by a barrier and a device synchronisation on both sides, MAX over
+ranks; the remaining k - K iterations then complete the decomposition outside the clock (config.k and steps are reported
+separately; --steps above the workload's k lengthens the decomposition to K).  N > 1: one process per GPU (torch.distributed.run), rows
 dealt to ranks by degree rank, the new Lanczos vector re-assembled each iteration by an RCCL all-gather
 inside liblzx.so (torch.distributed only carries the 128-byte communicator id, the barrier and the max).
 The same graph is used at every N, so scaling is "strong".
@@ -47,19 +50,37 @@ WORKLOADS = {
            "seed 1234", "rmat", 27, 100_000_000, 2_000_000_000, 1234, 30),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X datasheet, /opt/skills/guides/MI355X_MICROARCH.md
+EXIT_TRIAL_HUNG = 75   # the overlapped-exchange trial never completed (a hung collective): the held line is printed, the run is NOT a success
+
+
+def build_id() -> str:
+    """Hash of the kernel sources this run's liblzx.so was built from (csrc/*.hip, *.h, include/lzx.h; they travel with
+    the snapshot, .git does not): ties a bench line to the build, and the committed PMC traffic figure to the build it was
+    measured on (profiles/pmc_traffic.json carries the id of the profiled run's own bench line)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "msc-hpc-final-project_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "msc-hpc-final-project_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "lzx.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(workload: str, world: int):
     """HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (bench.py cannot wrap itself in the
-    profiler); None when no pass exists for this workload / rank count."""
+    profiler): (bytes, source, build id of the profiled run or None); all None when no pass exists for this workload /
+    rank count."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if world != 1 or not os.path.exists(path):
-        return None, None
+        return None, None, None
     try:
         d = json.load(open(path)).get(workload)
-        return (d["hbm_bytes_per_launch"], d["source"]) if d else (None, None)
+        return (d["hbm_bytes_per_launch"], d["source"], d.get("build_id")) if d else (None, None, None)
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def cpu_baseline(eng, O, budget_s: float = 20.0):
@@ -118,8 +139,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_pkg()
-    desc, kind, scale, n, draws, seed, _ = WORKLOADS[args.workload]
+    desc, kind, scale, n, draws, seed, k_workload = WORKLOADS[args.workload]
     K, W = args.steps, args.warmup
+    k_cfg = max(k_workload, K)   # the decomposition timed is BASELINE's k-step one; K of its iterations are on the clock
+    bid = build_id()
 
     # LZX_BENCH_REHEARSE_MULTI=1 (with torch.distributed.run --nproc-per-node 1): the N > 1 flow -- exchange tuning, both
     # engines, RCCL collectives on the 1-rank communicator -- on a box with one GPU.  A rehearsal of the code path, not
@@ -180,18 +203,26 @@ def main():
     x0 = np.ones(n)
 
     def measure(e):
-        """W untimed iterations, then exactly K timed ones between barrier + synchronise on both sides, max over ranks."""
+        """W untimed iterations (a decomposition of their own), then the workload's k-step decomposition is prepared and
+        exactly K of its iterations run between barrier + synchronise on both sides, max over ranks; the other k - K follow
+        outside the clock."""
         if W > 0:
             e.lanczos_prepare(x0, W)
             e.lanczos_run()
         t_in = time.perf_counter()
-        e.lanczos_prepare(x0, K)     # x0 uploaded, q_0 in HBM: inputs resident before the clock starts
+        e.lanczos_prepare(x0, k_cfg)     # x0 uploaded, q_0 in HBM, basis sized for k columns: inputs resident before the clock starts
         barrier(e)
         t_in = time.perf_counter() - t_in
         t0 = time.perf_counter()
-        st = e.lanczos_run()         # exactly K iterations; returns after a stream synchronise
+        st = e.lanczos_run_steps(K)      # exactly K iterations; returns after a stream synchronise
         barrier(e)
         elapsed = time.perf_counter() - t0
+        assert st["iters"] == K, st
+        t_rest = time.perf_counter()
+        if k_cfg > K:
+            e.lanczos_run_steps(k_cfg - K)
+        barrier(e)
+        t_rest = time.perf_counter() - t_rest
         m = {}
         if dist is not None:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -206,9 +237,10 @@ def main():
         else:
             m.update(spmv_ms_max=st["spmv_ms"], comm_ms=st["comm_ms"], vec_ms=st["vec_ms"], spmv_bytes_total=float(st["spmv_bytes"]))
         t_out = time.perf_counter()
-        alpha, beta, _ = e.lanczos_fetch(K)
+        alpha, beta, _ = e.lanczos_fetch(k_cfg)
         t_out = time.perf_counter() - t_out
-        m.update(elapsed=elapsed, t_in=t_in, t_out=t_out, finite=bool(np.isfinite(alpha).all() and np.isfinite(beta).all()))
+        m.update(elapsed=elapsed, t_in=t_in, t_out=t_out, t_rest=t_rest,
+                 finite=bool(np.isfinite(alpha).all() and np.isfinite(beta).all()))
         return m
 
     stream = None
@@ -238,7 +270,10 @@ def main():
             "config": {
                 "workload": desc,
                 "n": gi["n"], "undirected_edges": gi["nnz"] // 2, "nnz": gi["nnz"], "max_degree": gi["max_degree"],
-                "k": K, "x0": "ones",
+                "k": k_cfg, "x0": "ones",
+                "timed": f"iterations 0..{K - 1} of the k = {k_cfg} decomposition (lzx_lanczos_prepare_f64(x0, {k_cfg}), then "
+                         f"lzx_lanczos_run_steps({K}) on the clock; the other {k_cfg - K} run afterwards, outside it)",
+                "build_id": bid,
                 "partition": "single GPU" if world == 1 else
                              f"rows dealt round-robin by degree rank over {world} GPUs; per iteration {8 * gi['exchange_recv']} B "
                              f"received per rank over RCCL (slices of {8 * gi['exchange_slice']} B: only the {gi['active_vertices']} "
@@ -248,9 +283,9 @@ def main():
                 "exchange_tuning_ms_per_iter": dict(tune) or None,
                 "exchange_chunk0_doubles_per_rank": gi.get("exchange_chunk0", 0),
                 "graph_build_s": round(t_gen, 3),
-                # not `value`: the same K iterations with the host hand-over (x0 upload, basis set-up) and the download
-                # of alpha / beta included -- what a caller holding host buffers sees (rank 0's clock)
-                "iters_per_sec_including_host_transfers": K / (elapsed + m["t_in"] + m["t_out"]),
+                # not `value`: the whole k-step decomposition with the host hand-over (x0 upload, basis set-up) and the
+                # download of alpha / beta included -- what a caller holding host buffers sees (rank 0's clock)
+                "iters_per_sec_including_host_transfers": k_cfg / (elapsed + m["t_rest"] + m["t_in"] + m["t_out"]),
                 "lanczos_coefficients_finite": m["finite"],
             },
             "roofline": {
@@ -263,8 +298,13 @@ def main():
                 "peak": HBM_PEAK_GBS * world,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK_GBS * world),
+                # PMC bytes per SpMV from the committed rocprofv3 passes (a bench run cannot wrap itself in the profiler);
+                # traffic_build_id is the build_id of the profiled run's own bench line: equal to config.build_id when the
+                # figure was measured on this very build
                 "traffic": pmc_traffic(args.workload, world)[0],
                 "traffic_source": pmc_traffic(args.workload, world)[1],
+                "traffic_build_id": pmc_traffic(args.workload, world)[2],
+                "traffic_measured_on_this_build": pmc_traffic(args.workload, world)[2] == bid,
                 # the same box's own streaming rates (read-only sum / copy over 1 GiB, rank 0) and the SpMV against them
                 "measured_stream_read_GBps": stream[0], "measured_stream_copy_GBps": stream[1],
                 "frac_of_measured_stream_read": achieved / (stream[0] * world) if stream[0] else None,
@@ -292,16 +332,17 @@ def main():
         # iterations, rank aggregation -- is done in the single-all-gather mode FIRST and rank 0 holds its line; (2) the
         # overlapped mode is then tried for a few iterations under a watchdog and, if it is faster on the slowest rank,
         # measured in full and reported instead.  Whatever happens in (2) -- an error (every rank falls back) or a
-        # collective that never completes (the watchdog prints the held line and ends the process) -- the run still
-        # delivers the line of (1).  Nothing is re-executed from a GPU process.
+        # collective that never completes (the watchdog prints the held line and ends the process with EXIT_TRIAL_HUNG: a
+        # hang is a failure and shows in the return code) -- the run still delivers the line of (1).  Nothing is re-executed
+        # from a GPU process.
         def timed(e):
             best = float("inf")
             for _ in range(2):
-                e.lanczos_prepare(x0, 6)
+                e.lanczos_prepare(x0, k_cfg)
                 e.sync()
                 dist.barrier()
                 t = time.perf_counter()
-                e.lanczos_run()
+                e.lanczos_run_steps(6)
                 dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
                 best = min(best, float(dt.item()))
@@ -325,7 +366,7 @@ def main():
                       file=sys.stderr, flush=True)
                 if held is not None:
                     print(held, flush=True)
-                os._exit(0)
+                os._exit(EXIT_TRIAL_HUNG)   # every rank: a collective that never completes is not a successful run
 
         if os.environ.get("LZX_BENCH_SKIP_OVERLAP_TRIAL") == "1":
             alt = None

@@ -178,6 +178,7 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "long_row")) c->long_row_opt = value;
     else if (!strcmp(name, "item_len")) c->item_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
+    else if (!strcmp(name, "reference_order")) c->ref_order_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_set_shape: unknown shape '%s'", name);
     return LZX_OK;
 }
@@ -236,7 +237,7 @@ static int sync_all(std::vector<lzx_ctx *> &cs)
     return LZX_OK;
 }
 
-static int ensure_capacity(lzx_ctx *c, u32 k)
+static int ensure_capacity(lzx_ctx *c, u32 k, bool qf32)
 {
     LZX_HIP(hipSetDevice(c->device));
     if (k > c->k_cap) {
@@ -248,8 +249,12 @@ static int ensure_capacity(lzx_ctx *c, u32 k)
         LZX_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_beta), sizeof(double) * k));
         c->k_cap = k;
     }
-    if (c->qf32) {
-        // N4: the basis is stored as fp32; the recurrence's three live vectors stay fp64 (d_ring)
+    if (qf32) {
+        // N4: the basis is stored as fp32; the recurrence's three live vectors stay fp64 (d_ring).  The fp64 basis of an
+        // earlier decomposition on this handle goes first: the mode's point is half the HBM
+        if (c->d_Q) (void)hipFree(c->d_Q);
+        c->d_Q = nullptr;
+        c->q_cols = 0;
         if (k > c->qf_cols) {
             if (c->d_Qf) (void)hipFree(c->d_Qf);
             c->d_Qf = nullptr;
@@ -260,6 +265,14 @@ static int ensure_capacity(lzx_ctx *c, u32 k)
         for (double *&r : c->d_ring)
             if (!r) LZX_HIP(hipMalloc(reinterpret_cast<void **>(&r), sizeof(double) * c->ldq));
         return LZX_OK;
+    }
+    // ... and the fp32 form's buffers when the handle goes back to the fp64 basis
+    if (c->d_Qf) (void)hipFree(c->d_Qf);
+    c->d_Qf = nullptr;
+    c->qf_cols = 0;
+    for (double *&r : c->d_ring) {
+        if (r) (void)hipFree(r);
+        r = nullptr;
     }
     if (k > c->q_cols) {
         if (c->d_Q) (void)hipFree(c->d_Q);
@@ -275,6 +288,7 @@ static int ensure_capacity(lzx_ctx *c, u32 k)
 static bool loop_is_lazy(const lzx_ctx *c0)
 {
     if (c0->reorth_opt > 0) return false;   // R1 runs the reference's operation order on the normalised basis
+    if (c0->ref_order_opt > 0) return false;   // test shape: the reference's operation AND reduction order
     if (c0->qf32_opt > 0 && c0->lazy_opt != 0) return true;   // the fp32-stored basis lives in the lazy loop: asking for it selects it
     return c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (lzx_exchanges(c0) || c0->codes16));
 }
@@ -333,9 +347,21 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
         if (c->reorth_opt != c0->reorth_opt || c->qf32_opt != c0->qf32_opt) LZX_FAIL(LZX_ERR_STATE, "handles carry different loop options");
         if (c->qf32_opt > 0 && (!lazy || c->basis_u_opt == 0))
             LZX_FAIL(LZX_ERR_STATE, "basis_fp32 needs the lazy loop (not with lazy_normalisation = 0, not together with reorthogonalise)");
-        c->qf32 = c->qf32_opt > 0;
-        c->k_prep = 0;
+        if (c->ref_order_opt > 0 && (multi || cs.size() > 1 || c->reorth_opt > 0))
+            LZX_FAIL(LZX_ERR_STATE, "the reference_order test shape runs on one rank, without reorthogonalise");
     }
+    // From here on the resident basis of an earlier decomposition is gone (its buffers may be reallocated or change form):
+    // nothing is resident and nothing prepared until this call has succeeded on every handle -- a failure part-way leaves
+    // handles on which lzx_multout / lzx_lanczos_fetch report "no decomposition", not a stale or null basis.
+    for (lzx_ctx *c : cs) {
+        c->k_prep = 0;
+        c->k_last = c->k_done = 0;
+        c->ymon_valid = 0;
+        c->qf32 = false;
+    }
+    const bool want_qf32 = c0->qf32_opt > 0;
+    for (lzx_ctx *c : cs) LZX_TRY(ensure_capacity(c, k, want_qf32));
+    for (lzx_ctx *c : cs) c->qf32 = want_qf32;
 
     // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161) -- one dependent chain of
     // n additions (7 ms at n = 10 M), on a helper thread while this one sizes the basis, clears it and uploads x0 (a pageable
@@ -351,9 +377,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     })};
 
     for (lzx_ctx *c : cs) {
-        LZX_TRY(ensure_capacity(c, k));
-        c->k_last = c->k_done = 0;
-        c->ymon_valid = 0;
+        LZX_HIP(hipSetDevice(c->device));
         if (c->qf32) {
             for (double *r : c->d_ring) LZX_HIP(hipMemsetAsync(r, 0, sizeof(double) * c->ldq, c->stream));
         } else {
@@ -543,6 +567,10 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
         }
     }
     const u32 reorth = (!lazy && c0->reorth_opt > 0) ? (u32)c0->reorth_opt : 0u;
+    // Test shape reference_order: the three reductions in serial/'s order (lzx_kernels.hip: k_ref_*).  The scalars then
+    // arrive in d_scal[0 / 1] the way the several-rank loop's all-reduced ones do, and the vector kernels are the same.
+    const bool ref = !lazy && !multi && c0->ref_order_opt > 0;
+    const bool scal = multi || ref;   // alpha_j / ||v||^2 come as ONE device scalar each instead of block partials
     for (u32 j = j0; !lazy && j < j1; ++j) {
         LZX_TRY(mk.begin_iteration(j, every));
         // v = A q_j ; partials of alpha_j
@@ -558,6 +586,11 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
             const double *qj = c->d_Q + (size_t)j * c->ldq;
+            if (ref) {
+                LZX_TRY(lzx_launch_ref_spmv(c, qj, c->d_v));
+                LZX_TRY(lzx_launch_ref_dot(c, c->d_v, qj, c->d_scal + 0));   // alpha_j = <v, q_j>, left to right
+                continue;
+            }
             SpmvLaunch l{multi ? c->d_xbuf : qj, qj, c->d_v, c->d_partials};
             if (overlap && j > 0) l.chunk1_ready = c->ev_c1;
             LZX_TRY(lzx_launch_spmv(c, l));
@@ -602,7 +635,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
             // last step: only alpha_{k-1} is an output (the reference also updates v, then drops it)
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
-                if (multi) LZX_HIP(hipMemcpyAsync(c->d_alpha + j, c->d_scal + 0, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                if (scal) LZX_HIP(hipMemcpyAsync(c->d_alpha + j, c->d_scal + 0, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
                 else LZX_TRY(lzx_launch_reduce(c, re ? c->d_partials3 : c->d_partials, re ? np_re : np, c->d_alpha + j, 0));
             }
             LZX_TRY(mk.tick(CAT_VEC));
@@ -614,9 +647,10 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
             LZX_HIP(hipSetDevice(c->device));
             const double *qj = c->d_Q + (size_t)j * c->ldq;
             const double *qjm1 = j > 0 ? c->d_Q + (size_t)(j - 1) * c->ldq : nullptr;
-            LZX_TRY(lzx_launch_axpy_norm(c, c->d_v, qj, qjm1, multi ? c->d_scal + 0 : (re ? c->d_partials3 : c->d_partials),
-                                         multi ? 1 : (re ? np_re : lzx_spmv_partials(c)), c->d_alpha + j,
+            LZX_TRY(lzx_launch_axpy_norm(c, c->d_v, qj, qjm1, scal ? c->d_scal + 0 : (re ? c->d_partials3 : c->d_partials),
+                                         scal ? 1 : (re ? np_re : lzx_spmv_partials(c)), c->d_alpha + j,
                                          j > 0 ? c->d_beta + (j - 1) : nullptr, c->d_partials2, &np2));
+            if (ref) LZX_TRY(lzx_launch_ref_dot(c, c->d_v, c->d_v, c->d_scal + 1));   // ||v||^2, left to right (k_scale takes the root)
         }
         if (multi) LZX_TRY(mk.tick(CAT_VEC));   // one rank: a single mark after k_scale covers both vector kernels
 
@@ -632,7 +666,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
         for (lzx_ctx *c : cs) {
             LZX_HIP(hipSetDevice(c->device));
             LZX_TRY(lzx_launch_scale(c, c->d_v, c->d_Q + (size_t)(j + 1) * c->ldq,
-                                     multi ? c->d_scal + 1 : c->d_partials2, multi ? 1 : np2, c->d_beta + j));
+                                     scal ? c->d_scal + 1 : c->d_partials2, scal ? 1 : np2, c->d_beta + j));
         }
         LZX_TRY(mk.tick(CAT_VEC));
 

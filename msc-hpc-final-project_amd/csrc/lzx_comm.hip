@@ -101,11 +101,31 @@ extern "C" int lzx_comm_init_rank(lzx_handle c, const uint8_t id[128], int rank,
     // The exchange stream gets a communicator of its own: RCCL serialises the operations of ONE communicator in issue
     // order whatever streams they are given, so the sparse send / receive group of chunk 1 (stream2) would otherwise
     // queue behind -- or ahead of -- the two-double all-reduce of the main stream instead of overlapping it.
+    // ncclCommSplit is itself collective; whether the split communicator is USED must not be a per-rank decision (a rank on
+    // the parent and a peer on the split one would wait for each other for ever): all ranks agree on the outcome, and unless
+    // it succeeded everywhere everybody stays on the one communicator.
     c->nccl_comm2 = nullptr;
-    if (g_rccl.CommSplit) {
-        ncclComm_t comm2 = nullptr;
-        if (g_rccl.CommSplit(comm, 0, rank, &comm2, nullptr) == ncclSuccess && comm2) c->nccl_comm2 = comm2;
-    }
+    ncclComm_t comm2 = nullptr;
+    bool split_ok = false, all_ok = false;
+    if (g_rccl.CommSplit) split_ok = g_rccl.CommSplit(comm, 0, rank, &comm2, nullptr) == ncclSuccess && comm2;
+    LZX_TRY(lzx_comm_agree(c, g_rccl.CommSplit ? split_ok : false, &all_ok));
+    if (all_ok) c->nccl_comm2 = comm2;
+    else if (split_ok && comm2) (void)g_rccl.CommDestroy(comm2);
+    return LZX_OK;
+}
+
+int lzx_comm_agree(lzx_ctx *c, bool ok, bool *all_ok)
+{
+    *all_ok = ok;
+    if (c->comm_kind != 2 || !c->nccl_comm) return LZX_OK;
+    double v = ok ? 1.0 : 0.0;
+    LZX_HIP(hipSetDevice(c->device));
+    // d_scal[7]: allocated with the handle, so nothing here can fail for lack of memory
+    LZX_HIP(hipMemcpyAsync(c->d_scal + 7, &v, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    LZX_NCCL(g_rccl.AllReduce(c->d_scal + 7, c->d_scal + 7, 1, ncclDouble, ncclMin, static_cast<ncclComm_t>(c->nccl_comm), c->stream));
+    LZX_HIP(hipMemcpyAsync(&v, c->d_scal + 7, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LZX_HIP(hipStreamSynchronize(c->stream));
+    *all_ok = v == 1.0;
     return LZX_OK;
 }
 
@@ -355,7 +375,17 @@ int lzx_comm_check_sparse(lzx_ctx *c)
     }
     u32 *d = nullptr;
     LZX_HIP(hipSetDevice(c->device));
-    LZX_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(u32) * (mine.size() + all.size())));
+    // the staging buffer is a rank-local allocation in front of a collective: agree on it first (a rank that could not
+    // allocate would otherwise leave its peers in the all-gather below)
+    hipError_t ea = hipMalloc(reinterpret_cast<void **>(&d), sizeof(u32) * (mine.size() + all.size()));
+    if (ea != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+    bool all_ok = false;
+    const int rca = lzx_comm_agree(c, ea == hipSuccess, &all_ok);
+    if (rca != LZX_OK || !all_ok) {
+        if (d) (void)hipFree(d);
+        if (rca != LZX_OK) return rca;
+        LZX_FAIL(ea == hipSuccess ? LZX_ERR_STATE : LZX_ERR_NOMEM, "sparse exchange check: %s", ea == hipSuccess ? "a peer rank could not allocate its staging buffer" : hipGetErrorString(ea));
+    }
     hipError_t e = hipMemcpyAsync(d, mine.data(), sizeof(u32) * mine.size(), hipMemcpyHostToDevice, c->stream);
     ncclResult_t r = ncclSuccess;
     if (e == hipSuccess)

@@ -69,6 +69,15 @@ int lzx_graph_release(lzx_ctx *c)
     dev_free(c->d_u[0]);
     dev_free(c->d_u[1]);
     dev_free(c->d_Q);
+    // the other per-graph buffers of the loop's optional forms are sized by this graph's ldq / n_loc_pad too: a larger graph
+    // on the same handle must not inherit them (fp32-stored basis, its three live vectors, the convergence monitor's answers)
+    dev_free(c->d_Qf);
+    for (double *&r : c->d_ring) dev_free(r);
+    for (double *&y : c->d_ymon) dev_free(y);
+    c->qf_cols = 0;
+    c->qf32 = false;
+    c->k_done = 0;
+    c->ymon_valid = 0;
     dev_free(c->d_xbuf);
     dev_free(c->d_ybuf);
     dev_free(c->d_io);
@@ -570,6 +579,18 @@ int lzx_graph_prepare(lzx_ctx *c)
 #undef SX_HIP
         c->sparse = true;
         c->xlen = (u64)world * c->xs0 + round_up((u32)c->xc1, LZX_SLICE) + LZX_TAIL;
+    }
+    // ---- RCCL: the hand-over's one sync point.  Everything above is rank-local (allocations, sorts, scans) and may fail on
+    //      one rank alone; what follows it for the sparse chunk is a collective.  Every rank votes here -- one that failed
+    //      earlier through its hand-over entry point's lzx_agree_guard -- and all of them go on, or none does.
+    if (c->agree_pending) {
+        bool all_ok = false;
+        c->agree_pending = false;
+        rc = lzx_comm_agree(c, true, &all_ok);
+        if (rc != LZX_OK) { cleanup(); return rc; }
+        if (!all_ok) { cleanup(); LZX_FAIL(LZX_ERR_STATE, "graph hand-over: a peer rank failed while reshaping its share (see that rank's error)"); }
+    }
+    if (c->sparse) {
         rc = lzx_comm_check_sparse(c);   // RCCL: every pair of ranks agrees on what travels, or all of them fail here
         if (rc != LZX_OK) { cleanup(); return rc; }
     }
@@ -899,6 +920,7 @@ __global__ void k_gen_keys(int kind, u32 scale, u64 n, u64 draws, u64 seed, u32 
 extern "C" int lzx_set_graph_edges(lzx_handle c, uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst)
 {
     if (!c || (m && (!src || !dst)) || n == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_edges: bad argument");
+    lzx_agree_guard guard(c);   // RCCL: a local failure below still votes at the hand-over's sync point (lzx_internal.h)
     LZX_HIP(hipSetDevice(c->device));
     u32 *d_src = nullptr, *d_dst = nullptr, *d_bad = nullptr, bad = 0;
     u64 *d_keys = nullptr;
@@ -928,6 +950,7 @@ extern "C" int lzx_gen_graph(lzx_handle c, int kind, uint32_t scale, uint64_t n,
 {
     if (!c || n == 0 || (kind != 0 && kind != 1)) LZX_FAIL(LZX_ERR_ARG, "lzx_gen_graph: bad argument");
     if (kind == 1 && (scale == 0 || scale > 32 || n > (1ull << scale))) LZX_FAIL(LZX_ERR_ARG, "lzx_gen_graph: scale/n mismatch");
+    lzx_agree_guard guard(c);   // RCCL: a local failure below still votes at the hand-over's sync point (lzx_internal.h)
     LZX_HIP(hipSetDevice(c->device));
     u64 *d_keys = nullptr;
     LZX_TRY(dev_alloc(&d_keys, 2 * draws));
@@ -952,6 +975,7 @@ __global__ void k_check_cols(const u32 *col_idx, u64 nnz, u32 n, u32 *flag)
 static int set_csr_common(lzx_ctx *c, u64 n, u64 nnz, const u64 *row_ptr64, const u32 *row_ptr32, const u32 *col_idx)
 {
     if (!c || n == 0 || (!row_ptr64 && !row_ptr32) || (nnz && !col_idx)) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: bad argument");
+    lzx_agree_guard guard(c);   // RCCL: a local failure below still votes at the hand-over's sync point (lzx_internal.h)
     LZX_HIP(hipSetDevice(c->device));
     std::vector<u64> widened;
     if (!row_ptr64) {

@@ -97,6 +97,7 @@ struct lzx_ctx {
     double *d_mail = nullptr;          // [2][64][2]
     bool mail_ok = false;              // every peer's mailbox can be written from this handle's GPU
     void *nccl_comm2 = nullptr;        // the exchange stream's own communicator (ncclCommSplit of nccl_comm), or null
+    bool agree_pending = false;        // RCCL: a graph hand-over is under way and has not yet cast its vote at the sync point (lzx_agree_guard)
 
     // ---- whole graph, caller's vertex order (device) ----
     u64 n = 0, nnz = 0, max_degree = 0;
@@ -273,6 +274,10 @@ struct lzx_ctx {
     // orthogonalised against q_0 .. q_{j-2} (modified Gram-Schmidt, the reference's order) before alpha_j is taken; the
     // reference hard-codes e = 2.  0 / -1: off.  Runs the reference-order loop (normalised basis, every row elementwise).
     int64_t reorth_opt = -1;
+    // Test shape reference_order (lzx_test_set_shape; one rank): SpMV one lane per row of the caller's CSR, inner product and
+    // norm one left-to-right accumulator in the caller's vertex order -- the reduction orders serial/ fixes (SPMV.cc:24-27,
+    // lanczos.cc:155-171), so alpha / beta / Q meet the oracle's bit for bit at any k.  A parity instrument, not a fast path.
+    int64_t ref_order_opt = -1;
     // N4 remainder: the resident basis is STORED as fp32 (d_Qf), the recurrence keeps its three live vectors in fp64
     // (d_ring); lzx_multout and the host fetch read the fp32 columns.  Lazy loop only.  Off by default.
     int64_t qf32_opt = -1;
@@ -359,6 +364,10 @@ int lzx_launch_mgs_step(lzx_ctx *c, double *v, const double *q_m, const double *
                         const double *q_next, double *partials_out, u32 *np_out);
 // partial sums of |y - y_prev|^2 and |y|^2 over this rank's rows -> out2[0..1] (device)
 int lzx_launch_change(lzx_ctx *c, const double *y, const double *y_prev, double *out2);
+// reference-order test shape: y = A x one lane per caller's row (y, x in the internal layout); out = sum over the caller's
+// vertex order of a[i] * b[i], one accumulator (uses d_io as scratch)
+int lzx_launch_ref_spmv(lzx_ctx *c, const double *x, double *y);
+int lzx_launch_ref_dot(lzx_ctx *c, const double *a, const double *b, double *out);
 // column `col` of the fp32 basis, widened to fp64 into out[0..n_loc_pad)
 int lzx_launch_widen_col(lzx_ctx *c, u32 col, double *out);
 
@@ -373,6 +382,26 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
 int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
 int lzx_launch_sx_pack(lzx_ctx *c, const double *slice_loc, hipStream_t st);
 int lzx_comm_check_sparse(lzx_ctx *c);   // RCCL: all ranks' send / receive counts of the sparse chunk agree pairwise, or LZX_ERR_STATE everywhere
+// RCCL: every rank learns whether a rank-LOCAL step (an allocation, a sort, ...) failed on ANY rank -- a 1-value all-reduce
+// (min) on the handle's pre-allocated scalars -- before any of them enters the next collective; other transports: *all_ok = ok.
+int lzx_comm_agree(lzx_ctx *c, bool ok, bool *all_ok);
+// A graph hand-over over RCCL contains ONE such sync point (inside lzx_graph_prepare, ahead of the pairwise check of the
+// sparse lists).  A rank whose local steps fail BEFORE it must still cast its vote, or its peers wait there for ever: every
+// hand-over entry point holds a guard, whose destructor votes "failed" if the sync point was never reached.
+struct lzx_agree_guard {
+    lzx_ctx *c;
+    explicit lzx_agree_guard(lzx_ctx *c_) : c(c_) { if (c) c->agree_pending = c->comm_kind == 2 && lzx_exchanges(c); }
+    ~lzx_agree_guard()
+    {
+        if (c && c->agree_pending) {
+            bool all = false;
+            c->agree_pending = false;
+            (void)lzx_comm_agree(c, false, &all);
+        }
+    }
+    lzx_agree_guard(const lzx_agree_guard &) = delete;
+    lzx_agree_guard &operator=(const lzx_agree_guard &) = delete;
+};
 // N4: all-gather of the slices as fp32 into every handle's d_xbuf (converted back to fp64 there), main streams
 int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
 int lzx_launch_to_f32(lzx_ctx *c, const double *in, float *out, u64 count);

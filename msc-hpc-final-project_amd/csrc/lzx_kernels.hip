@@ -447,6 +447,91 @@ __global__ void k_widen_col(const float *in, double *out, u32 n)
 }
 
 // --------------------------------------------------------------------------------------------------
+// Reference-order test shape (lzx_test_set_shape "reference_order"; one rank): the loop's three reductions in the order
+// serial/ fixes, so that alpha, beta and the basis can be compared with it BIT FOR BIT at any k.  Not a fast path: a parity
+// instrument, run by tests only.
+//   k_ref_spmv      one lane per row of the caller's CSR, entries added one at a time in ascending column order starting from
+//                   0.0 -- serial/lib/SPMV.cc:24-27 and the thread-per-row cu_spMV1 (parallel-final/lib/cu_SPMV.cu:31-41).
+//                   The vectors live in the engine's internal order; gidx maps a caller's vertex to its position there.
+//   k_ref_products  prod[o] = a[gidx[o]] * b[gidx[o]], caller's order (the product rounded on its own: no FMA, as in the
+//                   reference's generic x86-64 build)
+//   k_ref_seqsum    ONE lane adds prod[0 .. n) left to right into one accumulator -- lanczosDecomp::inner_prod / norm,
+//                   serial/lib/lanczos.cc:155-171 -- the other lanes of its workgroup only stage chunks of prod in LDS
+__global__ void __launch_bounds__(256)
+k_ref_spmv(const u64 *row_ptr, const u32 *col_idx, const u32 *gidx, const double *x, double *y, u64 n)
+{
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    u64 e = row_ptr[r];
+    const u64 end = row_ptr[r + 1];
+    double acc = 0.0;
+    // sixteen entries' look-ups in flight, then added in order (the sum's order is the entries' order whatever the loads do)
+    for (; e + 16 <= end; e += 16) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = x[gidx[col_idx[e + u]]];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += t[u];
+    }
+    for (; e < end; ++e) acc += x[gidx[col_idx[e]]];
+    y[gidx[r]] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_ref_products(const double *a, const double *b, const u32 *gidx, double *prod, u64 n)
+{
+    const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n) {
+        const u32 g = gidx[o];
+        prod[o] = a[g] * b[g];
+    }
+}
+
+static constexpr u32 LZX_REF_CHUNK = 8192;   // doubles staged per round (64 KiB of LDS)
+__global__ void __launch_bounds__(1024)
+k_ref_seqsum(const double *prod, u64 n, double *out)
+{
+    __shared__ double sh[LZX_REF_CHUNK];
+    double acc = 0.0;
+    for (u64 base = 0; base < n; base += LZX_REF_CHUNK) {
+        const u32 cnt = (u32)(n - base < LZX_REF_CHUNK ? n - base : LZX_REF_CHUNK);
+        for (u32 i = threadIdx.x; i < cnt; i += 1024) sh[i] = prod[base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 i = 0;
+            for (; i + 16 <= cnt; i += 16) {
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = sh[i + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += t[u];
+            }
+            for (; i < cnt; ++i) acc += sh[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = acc;
+}
+
+int lzx_launch_ref_spmv(lzx_ctx *c, const double *x, double *y)
+{
+    // rows of the padding (and nothing else) are not written by the kernel
+    LZX_HIP(hipMemsetAsync(y, 0, sizeof(double) * c->ldq, c->stream));
+    if (c->n == 0) return LZX_OK;
+    hipLaunchKernelGGL(k_ref_spmv, dim3((u32)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->d_row_ptr, c->d_col_idx, c->d_gidx_of_old, x, y, c->n);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_ref_dot(lzx_ctx *c, const double *a, const double *b, double *out)
+{
+    if (c->n) hipLaunchKernelGGL(k_ref_products, dim3((u32)((c->n + 255) / 256)), dim3(256), 0, c->stream, a, b, c->d_gidx_of_old, c->d_io, c->n);
+    hipLaunchKernelGGL(k_ref_seqsum, dim3(1), dim3(1024), 0, c->stream, c->d_io, c->n, out);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+// --------------------------------------------------------------------------------------------------
 // launch wrappers
 static u32 vec_grid(const lzx_ctx *c)
 {

@@ -20,8 +20,30 @@ def test_workloads_and_traffic_sources():
     assert b.HBM_PEAK_GBS == 8000.0                      # MI355X_MICROARCH.md: HBM3E, 8 TB/s
     table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     for key in ("c3", "c2", "er"):
-        traffic, source = b.pmc_traffic(key, 1)
+        traffic, source, build = b.pmc_traffic(key, 1)
         assert traffic and traffic > 0 and source
         assert os.path.exists(os.path.join(ROOT, source.split(":")[0])), source    # the rocprofv3 summary it was taken from
         assert table[key]["hbm_bytes_per_launch"] == traffic
-    assert b.pmc_traffic("c3", 8) == (None, None) or b.pmc_traffic("c3", 8)[0] is None   # only measured on one GPU
+        # provenance: the figure names the build it was measured on, and the profile it cites holds the bench lines of that build
+        assert build and len(build) == 16, key
+        prof = json.load(open(os.path.join(ROOT, source.split(":")[0])))
+        assert {l["config"]["build_id"] for n_, l in prof["bench_lines"].items() if n_ != "bench_kt.json"} == {build}, key
+    assert b.pmc_traffic("c3", 8)[0] is None   # only measured on one GPU
+    assert len(b.build_id()) == 16 and b.build_id() == b.build_id()
+
+
+def test_traffic_kernels_exist_in_the_built_library():
+    """every kernel whose PMC bytes a traffic figure sums is a kernel of the library as built now (a figure from a build whose
+    kernels have since been renamed or removed must be regenerated)"""
+    import re
+    import subprocess
+    lib = os.path.join(ROOT, "msc-hpc-final-project_amd", "liblzx.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as ge
+        ge.build()
+    blob = open(lib, "rb").read()
+    table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for key, entry in table.items():
+        for kern in entry["kernels"]:
+            base = re.search(r"(k_[a-z0-9_]+)", kern).group(1)
+            assert base.encode() in blob, (key, kern)

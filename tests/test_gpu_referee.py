@@ -34,6 +34,33 @@ def _protocol(O, eng, rp, ci, n, k, name, small_ks, want_q):
     say("engine")
     a, b, Q, xn, st = eng.lanczos(x0, k, want_q=want_q)
     assert xn == xn_ref and st["iters"] == k and np.isfinite(a).all() and np.isfinite(b).all()
+    # the same graph through the product library's `reference_order` test shape -- SpMV one lane
+    # per row of the caller's CSR, inner product / norm one left-to-right accumulator (serial/lib/SPMV.cc:24-27,
+    # lanczos.cc:155-171).  With serial/'s reduction order the device loop must reproduce the oracle's restatement of serial/
+    # BIT FOR BIT at BASELINE's k = 50: all 50 alpha, all 49 beta, every entry of the basis.  So "within 1e-10 of serial/" holds
+    # literally (at 0) in that mode, and what separates the production mode from serial/ is the reduction order alone.
+    say("engine, reference_order shape")
+    import __graft_entry__ as ge
+    pkg = ge.load_pkg()
+    ref_eng = pkg.Engine(0, reference_order=1)
+    ref_eng.set_graph_csr(rp, ci)
+    ra, rb, _, rxn, _ = ref_eng.lanczos(x0, k, want_q=False)
+    assert rxn == xn_ref
+    assert np.array_equal(ra, a_ref), (name, "alpha", np.flatnonzero(ra != a_ref)[:4])
+    assert np.array_equal(rb, b_ref), (name, "beta", np.flatnonzero(rb != b_ref)[:4])
+    # the basis column by column (no second 4 GB copy at C3): unit coefficient vectors through the device multOut
+    for j in (0, 1, k // 2, k - 1):
+        e = np.zeros(k)
+        e[j] = 1.0
+        assert np.array_equal(ref_eng.multout(e), Q_ref[j]), (name, "basis column", j)
+    for cap in (None, 40.0):
+        d = rel_inf(ref_eng.multout(shift_weights(O, ra, rb, rxn, cap=cap)), shift_weights(O, a_ref, b_ref, xn_ref, cap=cap) @ Q_ref)
+        p = rel_inf(eng.multout(shift_weights(O, a, b, xn, cap=cap)), shift_weights(O, a_ref, b_ref, xn_ref, cap=cap) @ Q_ref)
+        print(f"{name} k={k} cap={cap}: reference_order shape vs oracle {d:.2e}; production mode vs oracle {p:.2e}; "
+              f"alpha / beta of the production mode differ from serial/'s by up to {np.abs(a - a_ref).max() / np.abs(a_ref).max():.2e} / "
+              f"{np.abs(b - b_ref).max() / np.abs(b_ref).max():.2e} (reduction order only)")
+        assert d <= REL_INF_TOL, (name, cap, d)      # north star, literally: within 1e-10 of serial/ (the multOut sums differ: 1e-15)
+    ref_eng.close()
     rows = []
     R0 = None
     for kk in list(small_ks) + [k]:

@@ -63,7 +63,13 @@ if len(sys.argv) > 3:
             if any(s in k for s in spmv) and "hbm_bytes_per_launch_corrected" in d}
     path = os.path.join(out_dir, "pmc_traffic.json")
     table = json.load(open(path)) if os.path.exists(path) else {}
+    # the build the counters were taken on: config.build_id of the profiled runs' own bench lines (bench.py hashes the kernel
+    # sources); a figure whose passes ran on different builds is not written
+    ids = {b.get("config", {}).get("build_id") for n_, b in bench.items() if n_ in ("bench_fetch.json", "bench_write.json")}
+    if len(ids) != 1 or None in ids:
+        sys.exit(f"FETCH_SIZE / WRITE_SIZE passes carry no single build id: {ids}")
     table[sys.argv[3]] = {
+        "build_id": ids.pop(),
         "kernels": kern, "hbm_bytes_per_launch": sum(kern.values()),
         "source": f"profiles/{tag}_pmc.json: sum over the kernels of one SpMV (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                   "separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; the doubling was checked on k_scale / "
