@@ -129,7 +129,6 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "spmv_wgs")) c->spmv_wgs_opt = value;
     else if (!strcmp(name, "pb_column_band")) c->pb_cb_opt = value;
     else if (!strcmp(name, "side_stream")) c->side_opt = value;
-    else if (!strcmp(name, "pb_persistent")) c->pb_persist_opt = value;
     else if (!strcmp(name, "pb_stamps")) c->pb_stamps_opt = value;
     else if (!strcmp(name, "pb_order")) c->pb_order_opt = value;
     else if (!strcmp(name, "spmv_deep")) c->deep_opt = value;
@@ -144,7 +143,6 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
     else if (!strcmp(name, "unnormalised_basis")) c->basis_u_opt = value;
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
-    else if (!strcmp(name, "pb_gather_tickets")) c->pb_g3_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
 #endif
@@ -1258,43 +1256,6 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
             fprintf(stderr, "[lzx gstamps]   wavefront 0, us per workgroup (p10 / p50 / p90): records+zeroing %.1f / %.1f / %.1f | streaming %.1f / %.1f / %.1f | barrier before fold %.1f / %.1f / %.1f | fold %.1f / %.1f / %.1f | GB/s per workgroup while streaming p50 %.1f\n",
                     pct(zr, 0.1), pct(zr, 0.5), pct(zr, 0.9), pct(sm, 0.1), pct(sm, 0.5), pct(sm, 0.9), pct(br, 0.1), pct(br, 0.5), pct(br, 0.9),
                     pct(fd, 0.1), pct(fd, 0.5), pct(fd, 0.9), pct(rate, 0.5));
-        }
-        if (c->d_pb_stamps) {
-            // per-workgroup time lines of the persistent passes (100 MHz ticks): when did workgroups start and end
-            std::vector<unsigned long long> h(3 * 4096);
-            LZX_HIP(hipMemcpy(h.data(), c->d_pb_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-            const char *nm[3] = {"scatter chunk 0", "scatter chunk 1", "gather"};
-            for (int q = 0; q < 3; ++q) {
-                std::vector<double> st, en, busy;
-                unsigned long long t0 = ~0ull;
-                u64 units = 0, restaged = 0, tred = 0, tplain = 0;
-                for (int w = 0; w < 1024; ++w) {
-                    const unsigned long long *r = &h[(size_t)q * 4096 + 4 * w];
-                    if (r[1] == 0) continue;
-                    t0 = std::min(t0, r[0]);
-                }
-                for (int w = 0; w < 1024; ++w) {
-                    const unsigned long long *r = &h[(size_t)q * 4096 + 4 * w];
-                    if (r[1] == 0) continue;
-                    st.push_back((r[0] - t0) * 0.01);
-                    en.push_back((r[1] - t0) * 0.01);
-                    busy.push_back((r[1] - r[0]) * 0.01);
-                    units += r[2] & 0xffffffffull;
-                    restaged += q < 2 ? r[2] >> 32 : 0;
-                    tred += r[3] & 0xffffffffull;
-                    tplain += r[3] >> 32;
-                }
-                if (en.empty()) continue;
-                std::sort(st.begin(), st.end());
-                std::sort(en.begin(), en.end());
-                std::sort(busy.begin(), busy.end());
-                auto pct = [](const std::vector<double> &v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
-                fprintf(stderr, "[lzx stamps] %s: %zu workgroups, %llu units, %llu restagings | start us: max %.1f | end us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | busy us: min %.1f p50 %.1f max %.1f\n",
-                        nm[q], en.size(), (unsigned long long)units, (unsigned long long)restaged, st.back(), en.front(), pct(en, 0.1),
-                        pct(en, 0.5), pct(en, 0.9), en.back(), busy.front(), pct(busy, 0.5), busy.back());
-                if (q < 2) fprintf(stderr, "[lzx stamps]   wavefront 0, mean over workgroups: reduced steps %.1f us, plain quads %.1f us\n",
-                                   tred * 0.01 / en.size(), tplain * 0.01 / en.size());
-            }
         }
     }
 #endif

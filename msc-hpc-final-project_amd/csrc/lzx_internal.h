@@ -202,16 +202,6 @@ struct lzx_ctx {
     u32 *d_pb_multi = nullptr;         // [pb_n_multi][4] row, first slot, items, slot stride: rows of bands cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows
     uint8_t *d_pb_long_multi = nullptr; // [n_long64] 1: the split row is also listed in d_pb_multi
-    u32 *d_pb_items2 = nullptr;        // [pb_n_items][8] the persistent gather pass's records, workgroup by workgroup:
-                                       // begin, end, first row, rows, slots per row, total slot or ~0, 0, 0
-    u32 *d_pb_seg = nullptr;           // [segments][5] static scatter schedule: band, first / last step, first / last quad
-    u32 *d_pb_seg_begin = nullptr;     // first segment of every scatter workgroup, schedule 0 then schedule 1 (each + 1 end entry)
-    u32 pb_seg_groups[2] = {0, 0};     // workgroups of the two schedules (bands of chunk 0 / the rest)
-    u32 pb_seg_first[2] = {0, 0};      // where each schedule starts in d_pb_seg_begin
-    u32 *d_pb_wg_begin = nullptr;      // [pb_gather_grid + 1] first record of each gather workgroup's fixed list
-    u32 *d_pb_queue = nullptr;         // [4] ticket counters of the persistent scatter pass: chunk 0, chunk 1
-    u32 pb_qbase[4] = {0, 0, 0, 0};    // value each counter will have when its next launch starts
-    unsigned long long *d_pb_stamps = nullptr;   // [3][4096] debug library, option pb_stamps: per-workgroup start / end ticks
     int64_t pb_stamps_opt = -1;
     unsigned long long *d_pb_gstamps = nullptr;  // [pb_gather_grid][8] debug library, option pb_stamps: the product gather pass's sections
     int64_t tie_sort_opt = -1;         // blocked mode: ties of the degree ranking broken by staged-column count (debug knob; 0 = by id)
@@ -224,23 +214,15 @@ struct lzx_ctx {
     int64_t pb_group_force_opt = -1;   // test hook: this many bands per group (2 .. 8; 1 = 8) whatever the graph's size
     int64_t pb_gwaves_opt = -1;        // wavefronts per gather workgroup (debug knob): 8 (default) or 4
     u32 pb_gather_block = 512;
-    int64_t pb_persist_opt = -1;       // persistent passes: -1/1 on, 0 = one workgroup per unit / static item lists
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;
-    // gather pass drawn from a ticket counter (k_pb_gather3, the product form)
-    bool pb_g3 = false;
-    u32 pb_g3_items = 0;
-    uint4 *d_pb_grec = nullptr;        // [pb_g3_items][8][2] fat records, longest item first, one per (item, wavefront)
-    double *d_pb_item_dot = nullptr;   // [pb_g3_items] alpha partial of every item (closed in item order by k_pb_finish)
-    u32 *d_pb_gqueue = nullptr;        // the ticket counter (never reset)
+    double *d_pb_item_dot = nullptr;   // [pb_n_dyn] alpha partial of every drawn item of the gather pass's dynamic tail (closed in ticket order by k_pb_finish)
     u32 pb_n_static = 0, pb_n_dyn = 0; // gather items dealt to workgroups by the host / drawn from d_pb_gcounter at run time (k_pb_gather)
     u32 *d_pb_gcounter = nullptr;      // the dynamic tail's ticket counter (back to 0 at the end of every launch)
     int64_t spmv_wgs_opt = -1;         // test shape spmv_wgs: at most this many workgroups of k_spmv / staged-columns workgroups of the shared launch
     int64_t pb_gather_nt_opt = -1;     // test shape pb_gather_nt: the gather pass's stream loads non-temporal (1) or cached (0); -1: by the stream's size
     int64_t pb_grid_cap_opt = -1;      // test shape pb_gather_grid: at most this many gather workgroups
     int64_t pb_dyn_opt = -1;           // test shape pb_dyn_share: per cent of the gather pass's cost left to the dynamic tail (-1: default)
-    u32 pb_gq_base = 0;                // its value when the next launch starts
-    int64_t pb_g3_opt = -1;            // debug knob pb_gather_tickets: 0 = the static longest-first lists (k_pb_gather)
     u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)
     u64 pbr_entries = 0;               // entries of the reduced runs
     uint4 *d_pbr_code = nullptr;       // [pbr_steps][64] scatter order: 8 x (column in band | piece-end flag) per lane

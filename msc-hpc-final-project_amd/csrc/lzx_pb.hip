@@ -242,8 +242,14 @@ k_pb_occurrence(const uint16_t *prow, const u32 *rstart_pad, const u32 *band_ste
     if (lane == 0 && m > 1) atomicMax(&band_rep[R], m);
 }
 
-// slot of padded position p in its wave-private y tile: row * rep + (occurrence mod rep); padding -> the tile's
-// spare slot (index LZX_PB_RB)
+// slot word of padded position p: slot | round << 10.  slot = row * rep + (occurrence mod rep) in the wave-private y tile, where
+// `occurrence` counts the earlier lanes of the SAME ds_add_f64 instruction that carry the same row (k_pb_occurrence); round =
+// occurrence / rep.  The gather pass adds round 0 with one instruction and every later round with an instruction of its own
+// (tile_add2), so no two lanes of one instruction ever add into the same address: the order of every sum is fixed by the
+// program, not by how the LDS unit resolves same-address lanes (round 4: bit-reproducibility by construction; until then
+// the replica was occurrence mod rep and the rare overflow shared a slot inside one instruction).  Padding values are
+// zeros (d_pb_val is cleared once and padding is never written with anything else): they go to slot 0, round 0, where
+// adding them changes nothing in whatever order.
 __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *rstart_pad, const u32 *band_rep, u32 nr,
                            u64 count, uint16_t *lslot)
 {
@@ -251,7 +257,7 @@ __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *
     if (p >= count) return;
     const u32 r = prow[p];
     if (r == 0xffffu) {
-        lslot[p] = (uint16_t)LZX_PB_RB;
+        lslot[p] = 0;
         return;
     }
     u32 lo = 0, hi = nr;   // band of p
@@ -260,7 +266,7 @@ __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *
         if (rstart_pad[mid] <= p) lo = mid; else hi = mid;
     }
     const u32 rep = band_rep[lo];
-    lslot[p] = (uint16_t)(r * rep + (occ[p] % rep));
+    lslot[p] = (uint16_t)((r * rep + (occ[p] % rep)) | ((occ[p] / rep) << 10));   // rows * rep <= 1024, occurrence < 64
 }
 
 
@@ -549,6 +555,42 @@ __device__ __forceinline__ u32 gld_slot2(const uint16_t *p)
     return NT ? __builtin_nontemporal_load(reinterpret_cast<const u32 *>(p)) : *reinterpret_cast<const u32 *>(p);
 }
 
+// One pair of ds_add_f64 instructions of the gather pass: the even and the odd values of a 128-value block (lane l holds values
+// 2 l and 2 l + 1 and their slot words, k_pb_slots).  Round 0 -- all but a handful of values -- is one instruction per half;
+// lanes whose value shares its slot with an earlier lane of the same instruction carry a later round and add with an
+// instruction of their own (wave-uniform branch, rare).  LDS operations of one wavefront execute in issue order, so every
+// slot receives its addends in program order.
+__device__ __forceinline__ void tile_add2(double *ytile, u32 sv, double ax, double ay)
+{
+    const u32 s0 = sv & 0xffffu, s1 = sv >> 16;
+    if (s0 < 1024u) atomicAdd(&ytile[s0], ax);
+    if (s1 < 1024u) atomicAdd(&ytile[s1], ay);
+    if (__ballot((s0 | s1) >= 1024u)) {
+        u32 r = 1;
+        unsigned long long more;
+        do {
+            if ((s0 >> 10) == r) atomicAdd(&ytile[s0 & 1023u], ax);
+            if ((s1 >> 10) == r) atomicAdd(&ytile[s1 & 1023u], ay);
+            more = __ballot((s0 >> 10) > r || (s1 >> 10) > r);
+            ++r;
+        } while (more);
+    }
+}
+// ... and one instruction of 64 consecutive values (the tail of a band)
+__device__ __forceinline__ void tile_add1(double *ytile, u32 s0, double a)
+{
+    if (s0 < 1024u) atomicAdd(&ytile[s0], a);
+    if (__ballot(s0 >= 1024u)) {
+        u32 r = 1;
+        unsigned long long more;
+        do {
+            if ((s0 >> 10) == r) atomicAdd(&ytile[s0 & 1023u], a);
+            more = __ballot((s0 >> 10) > r);
+            ++r;
+        } while (more);
+    }
+}
+
 template <bool STAMP, bool NT>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // four wavefronts per SIMD = two workgroups per CU: at most 128 VGPRs (the stamped build took 129 and ran one per CU)
 k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *item_dot, const u32 *band_row0, const u32 *band_rep,
@@ -658,16 +700,13 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                         sv[u] = gld_slot2<NT>(lslot + p);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
-                        atomicAdd(&ytile[sv[u] >> 16], av[u].y);
-                    }
+                    for (int u = 0; u < 8; ++u) tile_add2(ytile, sv[u], av[u].x, av[u].y);
                 }
                 {   // up to seven more blocks and the band's tail (< 128 values): all fetched before the first add
                     double2 av[7];
                     u32 sv[7];
                     double tv[2] = {0.0, 0.0};
-                    u32 ts[2] = {LZX_PB_RB, LZX_PB_RB};
+                    u32 ts[2] = {0u, 0u};
 #pragma unroll
                     for (int u = 0; u < 7; ++u) {
                         if (kb + u < blocks) {           // wave-uniform
@@ -686,14 +725,11 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     }
 #pragma unroll
                     for (int u = 0; u < 7; ++u) {
-                        if (kb + u < blocks) {
-                            atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
-                            atomicAdd(&ytile[sv[u] >> 16], av[u].y);
-                        }
+                        if (kb + u < blocks) tile_add2(ytile, sv[u], av[u].x, av[u].y);
                     }
-                    atomicAdd(&ytile[ts[0]], tv[0]);
+                    tile_add1(ytile, ts[0], tv[0]);
                     __builtin_amdgcn_wave_barrier();   // the tail goes 64 consecutive values per instruction, in order
-                    atomicAdd(&ytile[ts[1]], tv[1]);
+                    tile_add1(ytile, ts[1], tv[1]);
                 }
                 __builtin_amdgcn_wave_barrier();
                 GSTAMP(t_stream);
@@ -772,21 +808,20 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                 sv[u] = gld_slot2<NT>(lslot + p);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                atomicAdd(&ytile[sv[u] & 0xffffu], av[u].x);
-                atomicAdd(&ytile[sv[u] >> 16], av[u].y);
-            }
+            for (int u = 0; u < 8; ++u) tile_add2(ytile, sv[u], av[u].x, av[u].y);
         }
         for (; kb < blocks; kb += WAVES) {
             const u32 p = beg + kb * 128u + lane * 2;
             const double2 a = gld_val2<NT>(val + p);
             const u32 s = gld_slot2<NT>(lslot + p);
-            atomicAdd(&ytile[s & 0xffffu], a.x);
-            atomicAdd(&ytile[s >> 16], a.y);
+            tile_add2(ytile, s, a.x, a.y);
         }
         // the band's tail (< 128 values): 64 consecutive values per instruction, wavefront 0
         if (wv == 0)
-            for (u32 i = beg + blocks * 128u + lane; i < end; i += 64) atomicAdd(&ytile[lslot[i]], val[i]);
+            for (u32 i0 = beg + blocks * 128u; i0 < end; i0 += 64) {   // (every lane takes part in tile_add1's ballots)
+                const u32 i = i0 + lane;
+                tile_add1(ytile, i < end ? (u32)lslot[i] : 0u, i < end ? val[i] : 0.0);
+            }
         GSTAMP(t_stream);
         __syncthreads();
         GSTAMP(t_bar);
@@ -907,19 +942,9 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_rep);
     pb_free(c->d_pb_beg);
     pb_free(c->d_pb_items);
-    pb_free(c->d_pb_items2);
-    pb_free(c->d_pb_wg_begin);
-    pb_free(c->d_pb_seg);
-    pb_free(c->d_pb_seg_begin);
-    pb_free(c->d_pb_stamps);
     pb_free(c->d_pb_gstamps);
-    pb_free(c->d_pb_grec);
     pb_free(c->d_pb_item_dot);
-    pb_free(c->d_pb_gqueue);
     pb_free(c->d_pb_gcounter);
-    c->pb_g3 = false;
-    c->pb_gq_base = 0;
-    pb_free(c->d_pb_queue);
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
     pb_free(c->d_pb_long_multi);
@@ -931,8 +956,8 @@ void lzx_pb_release(lzx_ctx *c)
     c->pbr_steps = 0;
 }
 
-// block partials of alpha the blocked passes leave: the ticketed gather pass hands its per-item partials to k_pb_finish
-u32 lzx_pb_partials(const lzx_ctx *c) { return c->pb ? (c->pb_g3 ? 0u : c->pb_gather_grid) + c->pb_finish_grid : 0; }
+// block partials of alpha the blocked passes leave
+u32 lzx_pb_partials(const lzx_ctx *c) { return c->pb ? c->pb_gather_grid + c->pb_finish_grid : 0; }
 
 namespace {
 // ---- build helpers: every one leaves its temporaries to the caller's arena, which frees them on any exit ----------
@@ -1320,9 +1345,6 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     }
     ar.drop(d_plcol); ar.drop(d_qcband);
     LZX_TRY(pb_units(c, st, sstart, qstart, nb, unit_cap));
-#ifdef LZX_DEBUG_KNOBS
-    if (c->pb_persist_opt == 1) LZX_TRY(lzx_pbdbg_segments(c, st, sstart, qstart, nb, nsteps));   // static scatter schedule (experiment)
-#endif
     LZX_HIP(hipGetLastError());
 
     // 6. conflict-free LDS slots for the gather pass
@@ -1396,19 +1418,10 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(pb_alloc(&c->d_pb_beg, (u64)nr + 1));
     LZX_HIP(hipMemcpyAsync(c->d_pb_beg, rstart.data(), sizeof(u32) * ((size_t)nr + 1), hipMemcpyHostToDevice, st));
     const u32 group_cap = c->pb_group_opt >= 0 ? (u32)c->pb_group_opt : LZX_PB_GROUP;
-    // The gather pass walks static longest-first lists (k_pb_gather).  Tickets over fat records (k_pb_gather3, lzx_pb_dbg.hip)
-    // were built and measured in round 3 (A/B on one box, four processes each, profiles/r3_gather_ab.txt): the ticketed form
-    // balances perfectly -- every workgroup ends within 4 % of the last -- and still loses, C3 0.644 vs 0.630 ms per SpMV, C2
-    // 0.076 vs 0.068: what it saves in tail it pays in exposed round trips the compiler would not keep in flight (scalar
-    // record load, the store behind the item partial) and a second barrier per item.  Debug knob pb_gather_tickets = 1.
-    bool g3 = false;
-#ifdef LZX_DEBUG_KNOBS
-    g3 = c->pb_g3_opt > 0 && c->pb_gather_block == 512u && c->pb_persist_opt <= 0;
-#endif
-    c->pb_g3 = g3;
-    std::vector<u32> g3_out;      // items after grouping {R | first band, begin | bands, end | values, slot | marker}
-    std::vector<u64> g3_cost;
-    if (group_cap > 0 && c->pb_gather_block == 512u && c->pb_persist_opt <= 0) {
+    // The gather pass walks static longest-first lists (k_pb_gather).  (A ticketed form over fat records was built and measured
+    // in round 3 -- it balances perfectly and still loses, C3 0.644 vs 0.630 ms per SpMV: profiles/r3_gather_ab.txt -- and was
+    // removed with the other experiments in round 4.)
+    if (group_cap > 0 && c->pb_gather_block == 512u) {
         // Small bands (the low-degree end of the row order: thousands of bands of a few thousand values, each of which
         // cost a workgroup three dependent round trips and two barriers) are gathered by ONE wavefront each, up to eight
         // consecutive ones per item.  Then the items are dealt to the workgroups longest first, each to the workgroup with
@@ -1449,10 +1462,6 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             cost.push_back(std::max<u64>(10ull * vals + 24ull * rows, 80ull * widest) + 40000ull);
             i = j;
         }
-        if (g3) {   // (debug library only)
-            g3_out = out;
-            g3_cost = cost;
-        }
         const u32 G = c->pb_gather_grid;
         const size_t no = cost.size();
         std::vector<u32> order(no);
@@ -1465,7 +1474,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             const u64 share = c->pb_dyn_opt >= 0 ? (u64)std::min<int64_t>(90, c->pb_dyn_opt) : LZX_PB_DYN_SHARE;
             u64 all = 0, tail = 0;
             for (u64 x : cost) all += x;
-            if (!g3 && share > 0 && no > (c->pb_dyn_opt > 0 ? 1 : 2) * (size_t)G)
+            if (share > 0 && no > (c->pb_dyn_opt > 0 ? 1 : 2) * (size_t)G)
                 while (n_tail + G < no && (tail + cost[order[no - 1 - n_tail]]) * 100 <= all * share) tail += cost[order[no - 1 - n_tail++]];
         }
         const size_t n_dealt = no - n_tail;
@@ -1501,13 +1510,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         c->pb_n_items = (u32)(items.size() / 4);
     }
 #ifdef LZX_DEBUG_KNOBS
-    if (c->pb_persist_opt > 0) LZX_TRY(lzx_pbdbg_persist_records(c, st, items, row0, rep));   // experiment: persistent passes
-#endif
-#ifdef LZX_DEBUG_KNOBS
-    if (g3) LZX_TRY(lzx_pbdbg_g3_records(c, st, g3_out, g3_cost, items, row0, rep, rstart));
-#endif
-#ifdef LZX_DEBUG_KNOBS
-    if (c->pb_stamps_opt > 0 && c->pb_persist_opt <= 0) {   // per-workgroup section stamps of the product gather pass
+    if (c->pb_stamps_opt > 0) {   // per-workgroup section stamps of the product gather pass
         LZX_TRY(pb_alloc(&c->d_pb_gstamps, 8 * (u64)c->pb_gather_grid));
         LZX_HIP(hipMemsetAsync(c->d_pb_gstamps, 0, sizeof(unsigned long long) * 8 * c->pb_gather_grid, st));
     }
@@ -1545,7 +1548,6 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     (void)waves_per_wg;
     c->pb_finish_grid = (c->pb_n_multi + c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;   // + the split rows of k_spmv
-    if (c->pb_g3) c->pb_finish_grid = std::max<u32>(c->pb_finish_grid, (c->pb_g3_items + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK);   // + the gather pass's item partials
     if (c->pb_n_dyn) c->pb_finish_grid = std::max<u32>(c->pb_finish_grid, (c->pb_n_dyn + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK);   // + the drawn items' alpha partials
     return LZX_OK;
 }
@@ -1568,7 +1570,7 @@ bool lzx_pb_can_fuse(const lzx_ctx *c)
 {
     if (!c->pb || !(c->pb_cb == LZX_PB_CB || c->pb_cb == 8192)) return false;
 #ifdef LZX_DEBUG_KNOBS
-    if (c->pb_persist_opt > 0 || lzx_pbdbg_ablate() || (c->phase_mask_opt & (4 | 8))) return false;
+    if (c->phase_mask_opt & (4 | 8)) return false;
 #endif
     return true;
 }
@@ -1588,14 +1590,10 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     auto kern = c->pb_cb == 8192 ? k_pb_scatter<8192> : k_pb_scatter<LZX_PB_CB>;
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    // both libraries run one workgroup per unit / static item lists (k_pb_scatter, k_pb_gather); the persistent and ticketed
-    // forms and the ablation switches are experiments of the debug library (lzx_pb_dbg.hip): none was faster
-    int dbg_rc = LZX_OK;
+    // one workgroup per unit / static item lists (k_pb_scatter, k_pb_gather); persistent and ticketed forms were measured in
+    // rounds 2 and 3 (none was faster: profiles/NOTES.md) and removed in round 4
     auto scatter = [&](u32 u0, u32 u1, bool may_fuse) {
         if (u1 <= u0 && !(may_fuse && fuse && fused)) return;
-#ifdef LZX_DEBUG_KNOBS
-        if (lzx_pbdbg_scatter(c, u0, u1, x, &dbg_rc)) return;   // an experimental form of the pass ran (or failed: dbg_rc)
-#endif
         if (may_fuse && fuse && fused && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192) && u0 == 0) {
             // the staged-columns workgroups share the launch of the scatter units (k_pb_scatter_spmv)
             auto kf = c->pb_cb == 8192 ? k_pb_scatter_spmv<8192> : k_pb_scatter_spmv<LZX_PB_CB>;
@@ -1619,7 +1617,6 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     } else {
         scatter(0, c->pb_units, true);
     }
-    LZX_TRY(dbg_rc);
     if (c->trace && do_scatter) LZX_HIP(hipEventRecord(c->trace_ev[3], c->stream));
     if (!do_gather) {
         LZX_HIP(hipGetLastError());
@@ -1640,9 +1637,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     bool gathered = false;
 #ifdef LZX_DEBUG_KNOBS
     if (!(c->phase_mask_opt & 8)) {
-        gathered = lzx_pbdbg_gather(c, v, q_loc, partials, &dbg_rc);   // persistent / ticketed experiments
-        LZX_TRY(dbg_rc);
-        if (!gathered && c->pb_stamps_opt > 0 && c->d_pb_gstamps) {   // the product kernel with its section stamps
+        if (c->pb_stamps_opt > 0 && c->d_pb_gstamps) {   // the product kernel with its section stamps
             LZX_TRY(nt ? gather(k_pb_gather<true, true>, c->d_pb_gstamps) : gather(k_pb_gather<true, false>, c->d_pb_gstamps));
             gathered = true;
         }
@@ -1655,8 +1650,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     if (c->pb_finish_grid)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, c->d_item_first,
-                           c->d_long_partial, c->d_pb_long_multi, c->n_long64, v, q_loc, partials + (c->pb_g3 ? 0u : c->pb_gather_grid),
-                           (c->pb_g3 || c->pb_n_dyn) ? c->d_pb_item_dot : nullptr, c->pb_g3 ? c->pb_g3_items : c->pb_n_dyn);
+                           c->d_long_partial, c->d_pb_long_multi, c->n_long64, v, q_loc, partials + c->pb_gather_grid,
+                           c->pb_n_dyn ? c->d_pb_item_dot : nullptr, c->pb_n_dyn);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }

@@ -114,3 +114,41 @@ def test_csr_validation(pkg):
     with pytest.raises(pkg.LzxError):
         pkg.Engine(99)                                            # no such device
     eng.close()
+
+
+def test_larger_graph_on_a_handle_that_ran_the_optional_loop_forms(pkg, oracle):
+    """the fp32-stored basis, its three live fp64 vectors and the convergence monitor's two answers are
+    sized by the graph (ldq / n_loc_pad).  Handing a LARGER graph to the same handle must drop them with the graph -- otherwise
+    prepare's clears, k_lazy_update's fp32 stores and lzx_multout_change's writes run past the old allocations.  Also the
+    mode switch fp64 basis <-> fp32 basis on a resident graph (the representation not in use is freed) and a decomposition
+    after a failed one."""
+    from test_gpu_parity import shift_weights
+    O = oracle
+    small = O.gen_er(3000, 20000, 5)
+    large = O.gen_rmat(16, 60000, 900000, 12)
+    eng = pkg.Engine(0, propagation_blocking=1, hub_entries=64)
+    for rp, ci in (small, large, small, large):
+        n = len(rp) - 1
+        x0 = np.ones(n)
+        eng.set_graph_csr(rp, ci)
+        eng.set_option("basis_fp32", 1)
+        a32, b32, _, xn, _ = eng.lanczos(x0, 12, want_q=False)
+        t = shift_weights(O, a32, b32, xn)
+        assert eng.multout_change(t) == 1.0                    # first answer since the prepare
+        assert eng.multout_change(t) == 0.0                    # the same coefficients again: no change
+        y32 = eng.multout(t)
+        eng.set_option("basis_fp32", 0)                        # back to the fp64 basis on the resident graph
+        a64, b64, Q, xn64, _ = eng.lanczos(x0, 12)
+        assert np.array_equal(a32, a64) and np.array_equal(b32, b64) and xn == xn64   # the loop never reads a rounded column
+        y64 = eng.multout(t)
+        assert np.abs(y64 - t @ Q).max() <= 1e-12 * np.abs(y64).max()
+        assert np.abs(y32 - y64).max() <= 1e-6 * np.abs(y64).max()
+        assert eng.multout_change(t) == 1.0 and eng.multout_change(t) == 0.0
+        a_ref, b_ref, _, _ = O.lanczos(rp, ci, 3, x0, want_q=False)
+        assert abs(a64[0] - a_ref[0]) <= 1e-12 * abs(a_ref[0]) and abs(b64[0] - b_ref[0]) <= 1e-12 * abs(b_ref[0])
+    # a prepare that fails (k = 0) leaves a handle that reports "no decomposition", then works again
+    with pytest.raises(pkg.LzxError):
+        eng.lanczos_prepare(np.ones(eng.n), 0)
+    a, b, _, _, _ = eng.lanczos(np.ones(eng.n), 12, want_q=False)
+    assert np.array_equal(a, a64) and np.array_equal(b, b64)
+    eng.close()
