@@ -166,6 +166,7 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_run_align")) c->pb_align_opt = value;
     else if (!strcmp(name, "pb_taper")) c->pb_taper_opt = value;
     else if (!strcmp(name, "pb_dyn_share")) c->pb_dyn_opt = value;
+    else if (!strcmp(name, "pb_carry_scan")) c->pb_scan_opt = value;
     else if (!strcmp(name, "pb_gather_grid")) c->pb_grid_cap_opt = value;
     else if (!strcmp(name, "pb_gather_nt")) c->pb_gather_nt_opt = value;
     else if (!strcmp(name, "spmv_wgs")) c->spmv_wgs_opt = value;
@@ -177,6 +178,11 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "item_len")) c->item_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "reference_order")) c->ref_order_opt = value;
+    // the lazy loop's two other forms (rows without an edge elementwise instead of one scalar recurrence; q_j stored instead of
+    // the unnormalised u_j) and the staged-columns workgroups' place in the shared launch: all compiled into this library
+    else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
+    else if (!strcmp(name, "unnormalised_basis")) c->basis_u_opt = value;
+    else if (!strcmp(name, "fuse_staged")) c->fuse_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_set_shape: unknown shape '%s'", name);
     return LZX_OK;
 }

@@ -345,7 +345,50 @@ __global__ void __launch_bounds__(64) k_pbr_steps(const u32 *ssorted, const uint
 //   plain part: each wavefront walks its own contiguous share of the quads 64 at a time (lane = consecutive quad):
 //       contiguous loads, and 32-byte-per-lane stores that are contiguous inside a run; 4 quads per lane in flight.
 // (The LZX_ABLATE switches behind DESIGN.md's ablation numbers live in a copy of this body in lzx_pb_dbg.hip.)
-template <u32 CB>
+// Cross-lane moves of the reduced step's fixed-order carry (below): DPP controls of the GFX9 family -- row_shr:n moves inside a
+// row of 16 lanes, row_bcast:15 / row_bcast:31 hand the last lane of a row / of the first half on to the rows named by the
+// row mask, wave_shr:1 shifts the whole wavefront by one lane.  A lane without a source keeps the `old` operand: 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_u32(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// What holder lane L of a reduced step starts its running sum from: the tails (what follows a lane's last piece end; its whole
+// sum if it has none) of the lanes from the previous holder up to L - 1 -- a SEGMENTED inclusive scan over the lanes with the
+// holders as segment heads, shifted by one lane.  Six DPP steps (1, 2, 4, 8 inside the rows of 16, then across them), every
+// lane adding the same operands in the same order in every run: the sum's order is fixed by the program.
+__device__ __forceinline__ double pbr_carry_scan(double tail, bool has)
+{
+    double P = tail;
+    u32 F = has ? 1u : 0u;
+#define LZX_SCAN_STEP(CTRL, RM)                          \
+    {                                                    \
+        const double ps = dpp_f64<CTRL, RM>(P);          \
+        const u32 fs = dpp_u32<CTRL, RM>(F);             \
+        P = F ? P : P + ps;                              \
+        F |= fs;                                         \
+    }
+    LZX_SCAN_STEP(0x111, 0xf)   // row_shr:1
+    LZX_SCAN_STEP(0x112, 0xf)   // row_shr:2
+    LZX_SCAN_STEP(0x114, 0xf)   // row_shr:4
+    LZX_SCAN_STEP(0x118, 0xf)   // row_shr:8
+    LZX_SCAN_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+    LZX_SCAN_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+#undef LZX_SCAN_STEP
+    return dpp_f64<0x138, 0xf>(P);   // wave_shr:1: lane L takes lane L - 1's prefix (lane 0: nothing before it)
+}
+
+// SCAN: a row that spans lanes is summed across them by pbr_carry_scan (registers only, order fixed by the program);
+// otherwise through wave-private LDS carry slots (the round-1 .. 3 form: one ds_add_f64 per lane, whose same-slot lanes the
+// LDS unit orders).
+template <u32 CB, bool SCAN>
 __device__ __forceinline__ void
 pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
                 const double *__restrict__ x, u64 xlen, double *val, const u32 ublock)
@@ -366,7 +409,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
         for (u32 j = threadIdx.x; j < CB; j += 1024) tile[j] = base + j < xlen ? x[base + j] : 0.0;
     }
     if (threadIdx.x < 2) tile[CB + threadIdx.x] = 0.0;
-    for (u32 j = threadIdx.x; j < 16 * 66; j += 1024) tile[CB + 2 + j] = 0.0;   // the wavefronts' carry slots
+    if (!SCAN)
+        for (u32 j = threadIdx.x; j < 16 * 66; j += 1024) tile[CB + 2 + j] = 0.0;   // the wavefronts' carry slots
     __syncthreads();
     const u32 lane = threadIdx.x & 63;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -392,14 +436,20 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (e > last) tail += xv[e];
-            const unsigned long long holders = __ballot(has);
-            const unsigned long long before = holders & ((1ull << lane) - 1ull);
-            const u32 from = before ? 64u - (u32)__clzll((long long)before) : 0u;   // 1 + last holder before this lane
-            atomicAdd(&carry[has ? lane + 1 : from], tail);
-            __builtin_amdgcn_wave_barrier();
-            double s = has ? carry[from] : 0.0;
-            __builtin_amdgcn_wave_barrier();
-            if (has) carry[from] = 0.0;
+            double s;
+            if (SCAN) {
+                const double carried = pbr_carry_scan(tail, has);
+                s = has ? carried : 0.0;
+            } else {
+                const unsigned long long holders = __ballot(has);
+                const unsigned long long before = holders & ((1ull << lane) - 1ull);
+                const u32 from = before ? 64u - (u32)__clzll((long long)before) : 0u;   // 1 + last holder before this lane
+                atomicAdd(&carry[has ? lane + 1 : from], tail);
+                __builtin_amdgcn_wave_barrier();
+                s = has ? carry[from] : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                if (has) carry[from] = 0.0;
+            }
             double *out = val + pos;   // wave-uniform: the step's first value slot
             u32 done = 0;              // pieces of the planes before this one
 #pragma unroll
@@ -498,12 +548,12 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
     }
 }
 
-template <u32 CB>
+template <u32 CB, bool SCAN>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
              const double *__restrict__ x, u64 xlen, double *val)
 {
-    pb_scatter_body<CB>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
+    pb_scatter_body<CB, SCAN>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
 }
 
 // Scatter pass and staged-columns kernel in ONE launch (single GPU, 16 Ki bands): the persistent workgroups of the
@@ -513,7 +563,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
 // the launch ends with the small tapered units instead of a second ramp and drain; the other order (debug knob
 // fuse_staged = 1: staged columns behind the units, filling the scatter pass's tail while the write-back of its values
 // drains in their shadow) measures the same.  C3: SpMV 0.616 -> 0.601 ms against separate launches.
-template <u32 CB>
+template <u32 CB, bool SCAN>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
                   const double *__restrict__ x, u64 xlen, double *val, const SpmvArgs a, const u32 spmv_first)
@@ -521,10 +571,10 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
     const u32 spmv_blocks = gridDim.x - n_units;
     if (spmv_first) {
         if (blockIdx.x < spmv_blocks) spmv_body<2, false>(a, blockIdx.x, spmv_blocks);
-        else pb_scatter_body<CB>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x - spmv_blocks);
+        else pb_scatter_body<CB, SCAN>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x - spmv_blocks);
         return;
     }
-    if (blockIdx.x < n_units) pb_scatter_body<CB>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
+    if (blockIdx.x < n_units) pb_scatter_body<CB, SCAN>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
     else spmv_body<2, false>(a, blockIdx.x - n_units, spmv_blocks);
 }
 
@@ -591,7 +641,9 @@ __device__ __forceinline__ void tile_add1(double *ytile, u32 s0, double a)
     }
 }
 
-template <bool STAMP, bool NT>
+// NOSLOT (debug library, LZX_ABLATE_SLOTS=1: an ABLATION, wrong sums): the slot stream is not read at all -- what the pass
+// would cost if its 2 bytes per value came for free (lever i)
+template <bool STAMP, bool NT, bool NOSLOT = false>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // four wavefronts per SIMD = two workgroups per CU: at most 128 VGPRs (the stamped build took 129 and ran one per CU)
 k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *item_dot, const u32 *band_row0, const u32 *band_rep,
             const u32 *band_beg, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
@@ -697,7 +749,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     for (int u = 0; u < 8; ++u) {
                         const u32 p = beg + (kb + u) * 128u + lane * 2;
                         av[u] = gld_val2<NT>(val + p);
-                        sv[u] = gld_slot2<NT>(lslot + p);
+                        sv[u] = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) tile_add2(ytile, sv[u], av[u].x, av[u].y);
@@ -712,7 +764,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                         if (kb + u < blocks) {           // wave-uniform
                             const u32 p = beg + (kb + u) * 128u + lane * 2;
                             av[u] = gld_val2<NT>(val + p);
-                            sv[u] = gld_slot2<NT>(lslot + p);
+                            sv[u] = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
                         }
                     }
 #pragma unroll
@@ -805,7 +857,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
             for (int u = 0; u < 8; ++u) {
                 const u32 p = beg + (kb + u * WAVES) * 128u + lane * 2;
                 av[u] = gld_val2<NT>(val + p);
-                sv[u] = gld_slot2<NT>(lslot + p);
+                sv[u] = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) tile_add2(ytile, sv[u], av[u].x, av[u].y);
@@ -813,7 +865,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
         for (; kb < blocks; kb += WAVES) {
             const u32 p = beg + kb * 128u + lane * 2;
             const double2 a = gld_val2<NT>(val + p);
-            const u32 s = gld_slot2<NT>(lslot + p);
+            const u32 s = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
             tile_add2(ytile, s, a.x, a.y);
         }
         // the band's tail (< 128 values): 64 consecutive values per instruction, wavefront 0
@@ -1586,8 +1638,12 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         if (chunk1_ready && do_scatter) LZX_HIP(hipStreamWaitEvent(c->stream, chunk1_ready, 0));
         return LZX_OK;
     }
-    const size_t lds1 = ((size_t)c->pb_cb + 2 + 16 * 66) * sizeof(double);
-    auto kern = c->pb_cb == 8192 ? k_pb_scatter<8192> : k_pb_scatter<LZX_PB_CB>;
+    // a row that spans lanes of a reduced step: summed by a cross-lane scan in registers (test shape pb_carry_scan = 1) or
+    // through LDS carry slots (0)
+    const bool scan = c->pb_scan_opt >= 0 ? c->pb_scan_opt > 0 : LZX_PB_CARRY_SCAN;
+    const size_t lds1 = ((size_t)c->pb_cb + 2 + (scan ? 0 : 16 * 66)) * sizeof(double);
+    auto kern = c->pb_cb == 8192 ? (scan ? k_pb_scatter<8192, true> : k_pb_scatter<8192, false>)
+                                 : (scan ? k_pb_scatter<LZX_PB_CB, true> : k_pb_scatter<LZX_PB_CB, false>);
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     // one workgroup per unit / static item lists (k_pb_scatter, k_pb_gather); persistent and ticketed forms were measured in
@@ -1596,7 +1652,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         if (u1 <= u0 && !(may_fuse && fuse && fused)) return;
         if (may_fuse && fuse && fused && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192) && u0 == 0) {
             // the staged-columns workgroups share the launch of the scatter units (k_pb_scatter_spmv)
-            auto kf = c->pb_cb == 8192 ? k_pb_scatter_spmv<8192> : k_pb_scatter_spmv<LZX_PB_CB>;
+            auto kf = c->pb_cb == 8192 ? (scan ? k_pb_scatter_spmv<8192, true> : k_pb_scatter_spmv<8192, false>)
+                                       : (scan ? k_pb_scatter_spmv<LZX_PB_CB, true> : k_pb_scatter_spmv<LZX_PB_CB, false>);
             const size_t ldsf = std::max(lds1, c->spmv_lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             hipLaunchKernelGGL(kf, dim3(u1 + fuse_blocks), dim3(1024), ldsf, c->stream, c->d_pb_unit, u1, c->d_pbr_code, c->d_pbr_base,
@@ -1637,6 +1694,10 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     bool gathered = false;
 #ifdef LZX_DEBUG_KNOBS
     if (!(c->phase_mask_opt & 8)) {
+        if (getenv("LZX_ABLATE_SLOTS")) {   // ablation: the pass without its slot stream (wrong sums; timing only)
+            LZX_TRY(nt ? gather(k_pb_gather<false, true, true>, nullptr) : gather(k_pb_gather<false, false, true>, nullptr));
+            gathered = true;
+        } else
         if (c->pb_stamps_opt > 0 && c->d_pb_gstamps) {   // the product kernel with its section stamps
             LZX_TRY(nt ? gather(k_pb_gather<true, true>, c->d_pb_gstamps) : gather(k_pb_gather<true, false>, c->d_pb_gstamps));
             gathered = true;

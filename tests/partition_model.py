@@ -1,5 +1,5 @@
-"""Row partition of the multi-GPU Lanczos loop, stated in numpy (host-side mirror of the rules in
-csrc/lzx_graph.hip: lzx_graph_prepare steps 1-2).  Used by bench reporting and by the gloo tests that
+"""TEST INFRASTRUCTURE (moved out of the product package in round 4).  Row partition of the multi-GPU Lanczos loop, stated in numpy (host-side mirror of the rules in
+csrc/lzx_graph.hip: lzx_graph_prepare steps 1-2).  Used by the gloo tests (tests/test_distributed_gloo.py, tests/dist_model.py) that
 rehearse the N > 1 exchange pattern on CPU.
 
 Rules (identical on every rank, no communication needed to agree on them):

@@ -16,9 +16,30 @@ import __graft_entry__ as ge
 from test_gpu_parity import REL_INF_TOL, check_leading_coefficients, check_recurrence, rel_inf, shift_weights
 
 rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+# LZX_RANKS_ONE_GPU=1: all ranks on GPU 0 -- a probe of whether RCCL lets several ranks of one
+# communicator share a device (torch's own group runs over gloo then).  It does not: ncclCommInitRank fails with "Duplicate
+# GPU detected"; the probe prints the refusal and exits 0, so the answer is on record (profiles/r4_rccl_one_gpu.txt).
+one_gpu = os.environ.get("LZX_RANKS_ONE_GPU") == "1"
+if one_gpu:
+    local = 0
 torch.cuda.set_device(local)
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+if one_gpu:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+else:
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 pkg, O = ge.load_pkg(), ge.load_oracle()
+if one_gpu:
+    eng = pkg.Engine(0)
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid.copy_(torch.from_numpy(pkg.Engine.unique_id()))
+    dist.broadcast(uid, 0)
+    try:
+        eng.comm_init_rank(uid.numpy(), rank, world)
+        print(f"[rccl_ranks] rank {rank}: RCCL ACCEPTED {world} ranks on one GPU", flush=True)
+    except pkg.LzxError as exc:
+        print(f"[rccl_ranks] rank {rank}: RCCL_ONE_GPU_REFUSED: {exc}", flush=True)
+        sys.exit(0)
 rp, ci = O.gen_er(600000, 3000000, 77)
 n, k = len(rp) - 1, 10
 x0 = np.ones(n)
@@ -36,7 +57,7 @@ for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entr
              dict(propagation_blocking=1, hub_entries=1024, overlap_exchange=1, lazy_normalisation=0),
              dict(propagation_blocking=0, reorthogonalise=1), dict(propagation_blocking=1, hub_entries=1024, basis_fp32=1)):
     eng = pkg.Engine(local, **mode)
-    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    uid = torch.zeros(128, dtype=torch.uint8, device="cpu" if one_gpu else "cuda")
     if rank == 0:
         uid.copy_(torch.from_numpy(pkg.Engine.unique_id()))
     dist.broadcast(uid, 0)

@@ -30,7 +30,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as ge
     import importlib.util
-    spec = importlib.util.spec_from_file_location("lzx_partition", os.path.join(ge.PKG_DIR, "partition.py"))
+    spec = importlib.util.spec_from_file_location("lzx_partition", os.path.join(os.path.dirname(os.path.abspath(__file__)), "partition_model.py"))
     P = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(P)
     import dist_model
@@ -99,7 +99,7 @@ def test_two_rank_exchange_matches_single_process(oracle, tmp_path):
 def test_partition_rules(pkg):
     import importlib.util
     import __graft_entry__ as ge
-    spec = importlib.util.spec_from_file_location("lzx_partition", os.path.join(ge.PKG_DIR, "partition.py"))
+    spec = importlib.util.spec_from_file_location("lzx_partition", os.path.join(os.path.dirname(os.path.abspath(__file__)), "partition_model.py"))
     P = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(P)
     rp = np.array([0, 3, 3, 10, 11, 11, 20], dtype=np.uint64)   # degrees 3 0 7 1 0 9

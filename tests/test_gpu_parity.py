@@ -33,7 +33,9 @@ MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propag
          dict(propagation_blocking=1, hub_entries=64, pb_target=1024, pb_gather_grid=8, pb_dyn_share=40),
          # ... and the kernel large graphs get: stream loads non-temporal (chosen by the stream's size; forced here)
          dict(propagation_blocking=1, hub_entries=64, pb_target=2048, pb_group_force=4, pb_gather_grid=6, pb_dyn_share=60, pb_gather_nt=1),
-         dict(propagation_blocking=1, pb_gather_nt=1)]
+         dict(propagation_blocking=1, pb_gather_nt=1),
+         # the reduced step's cross-lane carry through LDS slots (rounds 1 - 3) instead of the fixed-order scan in registers
+         dict(propagation_blocking=1, hub_entries=64, pb_carry_scan=0), dict(propagation_blocking=1, pb_carry_scan=0, pb_target=2048)]
 
 
 def graphs(O):
@@ -99,7 +101,8 @@ def test_forced_shapes_run_the_product_library(pkg):
     gather groups -- is served by liblzx.so itself through its test-only entry lzx_test_set_shape (csrc/lzx_test_hooks.h),
     so the parity tests below meet the oracle with the machine code the bench runs; only experiment knobs select
     liblzx_dbg.so."""
-    for mode in MODES + [dict(exchange_at_world_1=1)]:
+    for mode in MODES + [dict(exchange_at_world_1=1), dict(isolated_rows=0), dict(unnormalised_basis=0), dict(fuse_staged=0), dict(fuse_staged=1),
+                         dict(reference_order=1)]:
         eng = pkg.Engine(0, **mode)
         assert eng.L is pkg.lib() and not eng.debug, mode
         eng.close()
@@ -437,6 +440,16 @@ def test_rccl_world1(oracle, pkg):
     a_ref, b_ref, _, _ = O.lanczos(rp, ci, 8, np.ones(n))
     check_leading_coefficients(a, b, a_ref, b_ref, "rccl1 overlapped")
     check_recurrence(O, rp, ci, a, b, Q, "rccl1 overlapped")
+    # Round 4: the hand-over's agreement point (lzx_comm_agree).  A rank-local failure BEFORE it -- here a column index out of
+    # range, caught by the validation that precedes the reshaping -- must still cast its vote (the entry point's
+    # lzx_agree_guard), come back as an error, and leave a handle and a communicator that work: the next hand-over, with its
+    # own vote and the pairwise check of the sparse lists behind it, succeeds.
+    bad = ci.copy()
+    bad[7] = n + 5
+    with pytest.raises(pkg.LzxError):
+        eng.set_graph_csr(rp, bad)
+    eng.set_graph_csr(rp, ci)
+    assert np.allclose(eng.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
     eng.close()
 
 
