@@ -115,6 +115,8 @@ def _load(path: str, mode: int) -> ctypes.CDLL:
     L.lzx_test_set_shape.argtypes = [_h, ctypes.c_char_p, ctypes.c_int64]
     L.lzx_test_get_shape.restype = ctypes.c_int
     L.lzx_test_get_shape.argtypes = [_h, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    L.lzx_test_rank_row_sums.restype = ctypes.c_int
+    L.lzx_test_rank_row_sums.argtypes = [_h, _f64p, _u32p, _u64p]
     return L
 
 
@@ -167,6 +169,20 @@ class Engine:
         v = ctypes.c_int64()
         _check(self.L.lzx_test_get_shape(self.h, name.encode(), ctypes.byref(v)), f"lzx_test_get_shape({name})", self.L)
         return int(v.value)
+
+    def rank_row_sums(self):
+        """test hook lzx_test_rank_row_sums: (row sums of this rank's own rows from its local SpMV of x = 1, caller's vertex id of
+        every local row) -- a rank's share checked without its peers"""
+        gi = self.info()
+        v = np.empty(max(gi["rows_local"], 1))
+        pos = np.empty(gi["n"], dtype=np.uint32)
+        pad = ctypes.c_uint64()
+        _check(self.L.lzx_test_rank_row_sums(self.h, _p(v, _f64p), _p(pos, _u32p), ctypes.byref(pad)), "lzx_test_rank_row_sums", self.L)
+        lo = gi["rank"] * pad.value
+        mine = np.flatnonzero((pos >= lo) & (pos < lo + gi["rows_local"]))
+        ids = np.empty(gi["rows_local"], dtype=np.int64)
+        ids[pos[mine].astype(np.int64) - lo] = mine
+        return v[:gi["rows_local"]], ids
 
     def close(self):
         if self.h:

@@ -199,6 +199,20 @@ extern "C" int lzx_test_get_shape(lzx_handle c, const char *name, int64_t *value
     return LZX_OK;
 }
 
+// test hook (csrc/lzx_test_hooks.h): one rank's local SpMV of x = 1, and where every vertex sits in the full-length layout
+extern "C" int lzx_test_rank_row_sums(lzx_handle c, double *v_local, uint32_t *layout_pos, uint64_t *n_loc_pad)
+{
+    if (!c || !v_local || !layout_pos || !n_loc_pad) LZX_FAIL(LZX_ERR_ARG, "lzx_test_rank_row_sums: bad argument");
+    if (!c->d_row_ptr || !c->d_v) LZX_FAIL(LZX_ERR_STATE, "no graph has been handed over");
+    double avg = 0.0;
+    LZX_TRY(lzx_bench_spmv(c, 1, &avg, nullptr));   // x = 1 in the layout this rank gathers from; leaves v = A x for its rows
+    LZX_HIP(hipSetDevice(c->device));
+    LZX_HIP(hipMemcpy(v_local, c->d_v, sizeof(double) * c->n_loc_real, hipMemcpyDeviceToHost));
+    LZX_HIP(hipMemcpy(layout_pos, c->d_gidx_of_old, sizeof(u32) * c->n, hipMemcpyDeviceToHost));
+    *n_loc_pad = c->n_loc_pad;
+    return LZX_OK;
+}
+
 // --------------------------------------------------------------------------------------------------
 static int gather_handles(lzx_handle h, std::vector<lzx_ctx *> &cs)
 {

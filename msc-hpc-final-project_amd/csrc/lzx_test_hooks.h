@@ -26,3 +26,12 @@ int lzx_test_set_shape(lzx_handle h, const char *name, int64_t value);
 extern "C"
 #endif
 int lzx_test_get_shape(lzx_handle h, const char *name, int64_t *value);
+// One rank's share checked without its peers (a rank of an in-process group whose other handles hold no graph; C5's rank
+// share on the one-GPU test box): this handle's LOCAL SpMV of x = 1 -- the row sums of its own rows, integers, exactly the
+// rows' degrees when its tables are right -- into v_local[0 .. rows_local), and the position of every vertex of the caller's
+// order in the full-length layout (rank * n_loc_pad + local row) into layout_pos[0 .. n), so that the caller can tell which
+// vertex a local row is.  Voids a prepared decomposition, like lzx_bench_spmv.
+#ifdef __cplusplus
+extern "C"
+#endif
+int lzx_test_rank_row_sums(lzx_handle h, double *v_local, uint32_t *layout_pos, uint64_t *n_loc_pad);

@@ -328,6 +328,23 @@ def test_c5_size_graph(pkg):
     assert 0 < gi["pb_values"] < gi["pb_entries"] < gi["nnz_local"] and gi["pb_reduced_entries"] > gi["pb_entries"] // 2
     avg, mn = e0.bench_spmv(3)
     assert 0 < mn <= avg
+    # the share itself, verified: rank 0's local SpMV of x = 1 must give the degree of every one of
+    # its 12.5 M rows exactly (integers) -- the staged tables, split rows, both blocked passes of THAT rank -- and the rows it
+    # owns are the degree ranks r with r % 8 == 0; then the same for rank 5, which generates and reshapes its own copy
+    degrees = None
+    for r, e in ((0, e0), (5, grp.engines[5])):
+        if r:
+            e.gen_rmat(scale, n, draws, 1234)
+        v, ids = e.rank_row_sums()
+        if degrees is None:
+            rp, _ = e.get_graph_csr()
+            degrees = np.diff(rp.astype(np.int64))
+            order = np.argsort(-degrees, kind="stable")
+            del rp
+        assert len(ids) == n // 8 and np.array_equal(np.sort(degrees[ids])[::-1], degrees[order[r::8]]), r   # the degree ranks r, r + 8, ...
+        assert np.array_equal(v, degrees[ids].astype(np.float64)), (r, int(np.flatnonzero(v != degrees[ids])[0]))
+        assert float(v.sum()) == float(e.info()["nnz_local"])
+    del degrees, order, v, ids
     grp.close()
 
     eng = pkg.Engine(0)
