@@ -365,8 +365,8 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
         if (c->reorth_opt != c0->reorth_opt || c->qf32_opt != c0->qf32_opt) LZX_FAIL(LZX_ERR_STATE, "handles carry different loop options");
         if (c->qf32_opt > 0 && (!lazy || c->basis_u_opt == 0))
             LZX_FAIL(LZX_ERR_STATE, "basis_fp32 needs the lazy loop (not with lazy_normalisation = 0, not together with reorthogonalise)");
-        if (c->ref_order_opt > 0 && (multi || cs.size() > 1 || c->reorth_opt > 0))
-            LZX_FAIL(LZX_ERR_STATE, "the reference_order test shape runs on one rank, without reorthogonalise");
+        if (c->ref_order_opt > 0 && (multi || cs.size() > 1))
+            LZX_FAIL(LZX_ERR_STATE, "the reference_order test shape runs on one rank");
     }
     // From here on the resident basis of an earlier decomposition is gone (its buffers may be reallocated or change form):
     // nothing is resident and nothing prepared until this call has succeeded on every handle -- a failure part-way leaves
@@ -631,8 +631,10 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
                     const double *qm = t == 0 ? nullptr : c->d_Q + (size_t)(t - 1) * c->ldq;
                     const double *qn = c->d_Q + (size_t)(t + 1 < j ? t : j) * c->ldq;
                     u32 npo = 0;
-                    LZX_TRY(lzx_launch_mgs_step(c, c->d_v, qm, multi ? nullptr : in, multi ? 0u : np_re, multi ? c->d_scal + 2 : nullptr, qn, out, &npo));
+                    LZX_TRY(lzx_launch_mgs_step(c, c->d_v, qm, scal ? nullptr : in, scal ? 0u : np_re, scal ? c->d_scal + 2 : nullptr, qn, out, &npo));
                     if (multi) LZX_TRY(lzx_launch_reduce(c, out, npo, c->d_scal + (t + 1 < j ? 2 : 0), 0));
+                    // reference_order: the inner product over the updated v, left to right (serial/lib/lanczos.cc:86-90, 163-171)
+                    if (ref) LZX_TRY(lzx_launch_ref_dot(c, c->d_v, qn, c->d_scal + (t + 1 < j ? 2 : 0)));
                     if (c == cs.back()) np_re = npo;
                 }
                 if (multi) LZX_TRY(lzx_comm_allreduce_sum(cs, t + 1 < j ? 2 : 0));

@@ -608,15 +608,23 @@ def test_reference_order_shape_is_bit_identical_to_the_oracle(pkg, oracle):
                 a2, b2, Q2 = eng.lanczos_fetch(k, want_q=True)
                 assert np.array_equal(a2, a_ref) and np.array_equal(b2, b_ref) and np.array_equal(Q2, Q_ref), (name, mode)
                 eng.close()
-    # several ranks, or together with the Arnoldi pass: refused, not silently something else
+    # several ranks: refused, not silently something else
     grp = pkg.LocalGroup([0, 0], reference_order=1)
     rp, ci = O.gen_er(10000, 100000, 1234)
     grp.set_graph_csr(rp, ci)
     with pytest.raises(pkg.LzxError):
         grp.lanczos(np.ones(10000), 4)
     grp.close()
-    eng = pkg.Engine(0, reference_order=1, reorthogonalise=1)
-    eng.set_graph_csr(rp, ci)
-    with pytest.raises(pkg.LzxError):
-        eng.lanczos(np.ones(10000), 4)
-    eng.close()
+    # R1 in the same shape: the Arnoldi pass of serial/lib/lanczos.cc:58-132 with its inner products left to right -- the
+    # restatement orc_lanczos_arnoldi bit for bit, for the reference's own schedule (every 2nd iteration) and for every one
+    for name, (rp, ci) in graphs(O):
+        n = len(rp) - 1
+        k = min(16, n - 1)
+        x0 = np.ones(n)
+        for every in (1, 2):
+            a_ref, b_ref, Q_ref, xn_ref = O.lanczos_arnoldi(rp, ci, k, x0, every=every)
+            eng = pkg.Engine(0, reference_order=1, reorthogonalise=every)
+            eng.set_graph_csr(rp, ci)
+            a, b, Q, xn, st = eng.lanczos(x0, k)
+            assert xn == xn_ref and np.array_equal(a, a_ref) and np.array_equal(b, b_ref) and np.array_equal(Q, Q_ref), (name, every)
+            eng.close()
