@@ -647,7 +647,7 @@ template <bool STAMP, bool NT, bool NOSLOT = false>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // four wavefronts per SIMD = two workgroups per CU: at most 128 VGPRs (the stamped build took 129 and ran one per CU)
 k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *item_dot, const u32 *band_row0, const u32 *band_rep,
             const u32 *band_beg, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
-            double *partials, unsigned long long *stamps)
+            double *partials, unsigned long long *stamps, const u32 probe_l2g)
 {
     unsigned long long t_start = 0, t_mark = 0, t_zero = 0, t_stream = 0, t_bar = 0, t_fold = 0, n_vals = 0;
     u32 n_it = 0;
@@ -783,6 +783,26 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     __builtin_amdgcn_wave_barrier();   // the tail goes 64 consecutive values per instruction, in order
                     tile_add1(ytile, ts[1], tv[1]);
                 }
+#ifdef LZX_DEBUG_KNOBS
+                if (probe_l2g) {
+                    // PROBE (debug library, LZX_PROBE_L2G = entries per small band; wrong sums, timing only): what would it cost the
+                    // pass to fetch some x values itself -- 8-byte gathers from a 1 MB window of x that stays in the L2s -- instead of
+                    // receiving them through the value stream?  probe_l2g look-ups per band, eight in flight per lane.
+                    const double *xt = q_loc + 16384;
+                    for (u32 i = lane; i < probe_l2g; i += 64 * 8) {
+                        double t8[8];
+                        u32 h8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            h8[u] = ((i + u * 64) * 2654435761u + r_row0 * 40503u) >> 7;
+                            t8[u] = xt[h8[u] & 0x1ffffu];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (i + u * 64 < probe_l2g) tile_add1(ytile, (h8[u] >> 17) % slots, t8[u]);
+                    }
+                }
+#endif
                 __builtin_amdgcn_wave_barrier();
                 GSTAMP(t_stream);
                 // fold: replicas in order; four rows per lane at a time, loads before stores
@@ -1684,11 +1704,15 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
                         16 * (LZX_PB_GATHER_BLOCK / 64) * 8 * sizeof(u32) + 16;   // tiles, wavefront sums, the preloaded item records, the ticket
     // stream loads of the pass as non-temporal loads when the value stream is larger than the caches can hold anyway (k_pb_gather)
     const bool nt = c->pb_gather_nt_opt >= 0 ? c->pb_gather_nt_opt > 0 : 10ull * c->pb_values > LZX_PB_NT_BYTES;
+    u32 probe_l2g = 0;
+#ifdef LZX_DEBUG_KNOBS
+    if (const char *pe = getenv("LZX_PROBE_L2G")) probe_l2g = (u32)atoi(pe);   // probe: extra L2-resident gathers per small band (k_pb_gather)
+#endif
     auto gather = [&](auto kern, unsigned long long *stamps) -> int {
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(kern, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_static, c->pb_n_dyn, c->d_pb_gcounter, c->d_pb_item_dot, c->d_pb_row0,
-                           c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, stamps);
+                           c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, stamps, probe_l2g);
         return LZX_OK;
     };
     bool gathered = false;
