@@ -251,7 +251,7 @@ k_pb_occurrence(const uint16_t *prow, const u32 *rstart_pad, const u32 *band_ste
 // zeros (d_pb_val is cleared once and padding is never written with anything else): they go to slot 0, round 0, where
 // adding them changes nothing in whatever order.
 __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *rstart_pad, const u32 *band_rep, u32 nr,
-                           u64 count, uint16_t *lslot)
+                           u64 count, uint16_t *lslot, const u32 no_rounds /* debug A/B only: same-slot lanes left to the LDS unit, as in rounds 1 - 3 */)
 {
     const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= count) return;
@@ -266,7 +266,7 @@ __global__ void k_pb_slots(const uint16_t *prow, const uint8_t *occ, const u32 *
         if (rstart_pad[mid] <= p) lo = mid; else hi = mid;
     }
     const u32 rep = band_rep[lo];
-    lslot[p] = (uint16_t)((r * rep + (occ[p] % rep)) | ((occ[p] / rep) << 10));   // rows * rep <= 1024, occurrence < 64
+    lslot[p] = (uint16_t)((r * rep + (occ[p] % rep)) | (no_rounds ? 0u : (occ[p] / rep) << 10));   // rows * rep <= 1024, occurrence < 64
 }
 
 
@@ -605,16 +605,22 @@ __device__ __forceinline__ u32 gld_slot2(const uint16_t *p)
     return NT ? __builtin_nontemporal_load(reinterpret_cast<const u32 *>(p)) : *reinterpret_cast<const u32 *>(p);
 }
 
-// One pair of ds_add_f64 instructions of the gather pass: the even and the odd values of a 128-value block (lane l holds values
-// 2 l and 2 l + 1 and their slot words, k_pb_slots).  Round 0 -- all but a handful of values -- is one instruction per half;
-// lanes whose value shares its slot with an earlier lane of the same instruction carry a later round and add with an
-// instruction of their own (wave-uniform branch, rare).  LDS operations of one wavefront execute in issue order, so every
-// slot receives its addends in program order.
-__device__ __forceinline__ void tile_add2(double *ytile, u32 sv, double ax, double ay)
+// The gather pass's LDS adds.  A slot word is slot | round << 10 (k_pb_slots): values of one ds_add_f64 instruction that share a
+// slot carry different rounds, so that no two lanes of one instruction ever add into the same address and every slot receives
+// its addends in program order (LDS operations of one wavefront execute in issue order).
+//   tile_add2: one pair of instructions -- the even and the odd values of a 128-value block, lane l holding values 2 l and
+//     2 l + 1.  Round 0 is branch-free and costs one instruction per value more than a plain add: a word of a later round is
+//     >= 1024 and is clamped to the lane's own spare slot behind the tile, where its value lands harmlessly (the spare slots
+//     are never read).  Later rounds -- a second value of a row inside one instruction is common, consecutive runs of a row
+//     band cover the same rows: 20 - 90 % of the blocks hold one -- follow behind ONE wave-uniform branch per pair, each round an
+//     instruction of its own.  (Measured on the 1 M-vertex graph, whose 16 us pass is latency-bound: exec-masked round-0 adds
+//     + 10 us, a batch-wide slow path of sixteen masked adds per round + 7 us, rounds 0 and 1 both branch-free + 7 us.)
+__device__ __forceinline__ void tile_add2(double *ytile, u32 lane, u32 sv, double ax, double ay)
 {
     const u32 s0 = sv & 0xffffu, s1 = sv >> 16;
-    if (s0 < 1024u) atomicAdd(&ytile[s0], ax);
-    if (s1 < 1024u) atomicAdd(&ytile[s1], ay);
+    const u32 spare = LZX_PB_RB + lane;
+    atomicAdd(&ytile[min(s0, spare)], ax);
+    atomicAdd(&ytile[min(s1, spare)], ay);
     if (__ballot((s0 | s1) >= 1024u)) {
         u32 r = 1;
         unsigned long long more;
@@ -627,9 +633,9 @@ __device__ __forceinline__ void tile_add2(double *ytile, u32 sv, double ax, doub
     }
 }
 // ... and one instruction of 64 consecutive values (the tail of a band)
-__device__ __forceinline__ void tile_add1(double *ytile, u32 s0, double a)
+__device__ __forceinline__ void tile_add1(double *ytile, u32 lane, u32 s0, double a)
 {
-    if (s0 < 1024u) atomicAdd(&ytile[s0], a);
+    atomicAdd(&ytile[min(s0, LZX_PB_RB + lane)], a);
     if (__ballot(s0 >= 1024u)) {
         u32 r = 1;
         unsigned long long more;
@@ -656,7 +662,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
     if (STAMP) { t_start = t_mark = wall_clock64(); c_start = __builtin_amdgcn_s_memtime(); }
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr u32 WAVES = LZX_PB_GATHER_BLOCK / 64;
-    constexpr u32 TILE = LZX_PB_RB + 8;                  // + spare slot for padding entries
+    constexpr u32 TILE = LZX_PB_RB + 64;                 // + one spare slot per lane (tile_add2)
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wv = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     double *ytile = lds + (size_t)wv * TILE;             // private to this wavefront
@@ -707,11 +713,17 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
         if (it < limit) item = items[it];
         o[5] = item.w;
         o[6] = 0u;
+        o[7] = 1u;
         if (item.w == LZX_PB_ITEM_GROUP) {
-            if (w < item.y) {
-                const u32 R = item.x + w;
+            // a group of item.y <= 8 small bands.  With fewer than five of them (small graphs, rank shares: one round of small
+            // bands per workgroup) the idle wavefronts help: every band is streamed by `split` wavefronts, each into its own
+            // tile -- wavefront w takes part w / y of band w % y -- and folded by its first one
+            const u32 y = item.y, split = y <= 1u ? 8u : y <= 2u ? 4u : y <= 4u ? 2u : 1u;
+            o[7] = split;
+            if (w < y * split) {
+                const u32 R = item.x + w % y;
                 const u32 r0 = band_row0[R];
-                o[0] = band_beg[R]; o[1] = band_beg[R + 1]; o[2] = r0; o[3] = band_row0[R + 1] - r0; o[4] = band_rep[R]; o[6] = 1u;
+                o[0] = band_beg[R]; o[1] = band_beg[R + 1]; o[2] = r0; o[3] = band_row0[R + 1] - r0; o[4] = band_rep[R]; o[6] = 1u + (w / y) + (y << 8);
             }
         } else if (item.w != LZX_PB_ITEM_NONE) {
             const u32 R = item.x;
@@ -725,44 +737,47 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
     for (u32 rr = 0; rr < nrounds && base + rr * stride < limit; ++rr) {
         const u32 *rec = lrec + ((size_t)rr * WAVES + wv) * 8;
         const u32 r_beg = uni(rec[0]), r_end = uni(rec[1]), r_row0 = uni(rec[2]), r_rows = uni(rec[3]), r_rep = uni(rec[4]);
-        const u32 item_w = uni(rec[5]), r_live = uni(rec[6]);
+        const u32 item_w = uni(rec[5]), r_live = uni(rec[6]), r_split = uni(rec[7]);
         if (item_w == LZX_PB_ITEM_NONE) continue;   // filler of the balanced schedule
         if (item_w == LZX_PB_ITEM_GROUP) {
-            // a group of up to eight SMALL consecutive bands, one per wavefront: each wavefront streams its own band into
-            // its own tile and folds it itself -- no workgroup barrier, no cross-wavefront fold, eight bands' round trips
-            // in flight per workgroup (the low-degree end of the row order is thousands of bands of a few thousand values)
+            // a group of up to eight SMALL consecutive bands: each wavefront streams its band -- or, in a group of few bands, its
+            // part of one (r_split wavefronts per band, blocks dealt round-robin) -- into its own tile; the band's first wavefront
+            // folds.  Eight bands: no workgroup barrier, no cross-wavefront fold, eight bands' round trips in flight per workgroup
+            // (the low-degree end of the row order is thousands of bands of a few thousand values); fewer: one barrier before the
+            // fold, and a band's serial chain of batches is r_split times shorter (1 M-vertex graph: the pass's critical path).
             __syncthreads();                 // the previous item's fold (it reads every wavefront's tile) is done
+            const u32 part = r_live ? (r_live & 0xffu) - 1u : 0u, gy = r_live >> 8;
             if (r_live) {
-                const u32 row0 = r_row0, rows = r_rows, rep = r_rep;
+                const u32 rows = r_rows, rep = r_rep;
                 const u32 beg = r_beg, end = r_end;
                 const u32 slots = rows * rep;
                 for (u32 j = lane; j < slots; j += 64) ytile[j] = 0.0;
                 __builtin_amdgcn_wave_barrier();
-                if (STAMP) { ++n_it; n_vals += end - beg; }
+                if (STAMP && part == 0) { ++n_it; n_vals += end - beg; }
                 GSTAMP(t_zero);
                 const u32 blocks = (end - beg) / 128u;
-                u32 kb = 0;
-                for (; kb + 8 <= blocks; kb += 8) {
+                u32 kb = part;
+                for (; kb + 7 * r_split < blocks; kb += 8 * r_split) {
                     double2 av[8];
                     u32 sv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const u32 p = beg + (kb + u) * 128u + lane * 2;
+                        const u32 p = beg + (kb + u * r_split) * 128u + lane * 2;
                         av[u] = gld_val2<NT>(val + p);
                         sv[u] = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) tile_add2(ytile, sv[u], av[u].x, av[u].y);
+                    for (int u = 0; u < 8; ++u) tile_add2(ytile, lane, sv[u], av[u].x, av[u].y);
                 }
-                {   // up to seven more blocks and the band's tail (< 128 values): all fetched before the first add
+                {   // up to seven more blocks and (the band's first wavefront) the band's tail (< 128 values): all fetched before the first add
                     double2 av[7];
                     u32 sv[7];
                     double tv[2] = {0.0, 0.0};
                     u32 ts[2] = {0u, 0u};
 #pragma unroll
                     for (int u = 0; u < 7; ++u) {
-                        if (kb + u < blocks) {           // wave-uniform
-                            const u32 p = beg + (kb + u) * 128u + lane * 2;
+                        if (kb + u * r_split < blocks) {           // wave-uniform
+                            const u32 p = beg + (kb + u * r_split) * 128u + lane * 2;
                             av[u] = gld_val2<NT>(val + p);
                             sv[u] = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
                         }
@@ -770,18 +785,18 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const u32 i = beg + blocks * 128u + lane + u * 64;
-                        if (i < end) {
+                        if (part == 0 && i < end) {
                             tv[u] = val[i];
                             ts[u] = lslot[i];
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 7; ++u) {
-                        if (kb + u < blocks) tile_add2(ytile, sv[u], av[u].x, av[u].y);
+                        if (kb + u * r_split < blocks) tile_add2(ytile, lane, sv[u], av[u].x, av[u].y);   // (wave-uniform)
                     }
-                    tile_add1(ytile, ts[0], tv[0]);
+                    tile_add1(ytile, lane, ts[0], tv[0]);
                     __builtin_amdgcn_wave_barrier();   // the tail goes 64 consecutive values per instruction, in order
-                    tile_add1(ytile, ts[1], tv[1]);
+                    tile_add1(ytile, lane, ts[1], tv[1]);
                 }
 #ifdef LZX_DEBUG_KNOBS
                 if (probe_l2g) {
@@ -799,13 +814,19 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
-                            if (i + u * 64 < probe_l2g) tile_add1(ytile, (h8[u] >> 17) % slots, t8[u]);
+                            if (i + u * 64 < probe_l2g) tile_add1(ytile, lane, (h8[u] >> 17) % slots, t8[u]);
                     }
                 }
 #endif
                 __builtin_amdgcn_wave_barrier();
                 GSTAMP(t_stream);
-                // fold: replicas in order; four rows per lane at a time, loads before stores
+                __builtin_amdgcn_wave_barrier();
+                GSTAMP(t_stream);
+            }
+            if (r_split > 1u) __syncthreads();   // (wave-uniform per item: every wavefront of the workgroup passes here) the partner tiles are complete
+            if (r_live && part == 0u) {
+                const u32 row0 = r_row0, rows = r_rows, rep = r_rep;
+                // fold: the band's tiles in wavefront order, replicas in order; four rows per lane at a time, loads before stores
                 for (u32 j0 = lane; j0 < rows; j0 += 256) {
                     double vv[4], qq[4];
 #pragma unroll
@@ -819,7 +840,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                         const u32 j = j0 + u * 64;
                         if (j < rows) {
                             double y = 0.0;
-                            for (u32 t = 0; t < rep; ++t) y += ytile[j * rep + t];
+                            for (u32 pt = 0; pt < r_split; ++pt)
+                                for (u32 t = 0; t < rep; ++t) y += ytile[(size_t)pt * gy * TILE + j * rep + t];
                             v[row0 + j] = vv[u] + y;
                             dot += y * qq[u];
                         }
@@ -880,19 +902,19 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                 sv[u] = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) tile_add2(ytile, sv[u], av[u].x, av[u].y);
+            for (int u = 0; u < 8; ++u) tile_add2(ytile, lane, sv[u], av[u].x, av[u].y);
         }
         for (; kb < blocks; kb += WAVES) {
             const u32 p = beg + kb * 128u + lane * 2;
             const double2 a = gld_val2<NT>(val + p);
             const u32 s = NOSLOT ? (lane * 2u) | ((lane * 2u + 1u) << 16) : gld_slot2<NT>(lslot + p);
-            tile_add2(ytile, s, a.x, a.y);
+            tile_add2(ytile, lane, s, a.x, a.y);
         }
         // the band's tail (< 128 values): 64 consecutive values per instruction, wavefront 0
         if (wv == 0)
             for (u32 i0 = beg + blocks * 128u; i0 < end; i0 += 64) {   // (every lane takes part in tile_add1's ballots)
                 const u32 i = i0 + lane;
-                tile_add1(ytile, i < end ? (u32)lslot[i] : 0u, i < end ? val[i] : 0.0);
+                tile_add1(ytile, lane, i < end ? (u32)lslot[i] : 0u, i < end ? val[i] : 0.0);
             }
         GSTAMP(t_stream);
         __syncthreads();
@@ -1450,8 +1472,48 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
             rep[R] = std::max(1u, std::min(std::min(rep[R], room), 64u));
         }
         LZX_HIP(hipMemcpyAsync(c->d_pb_rep, rep.data(), sizeof(u32) * nr, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_pb_slots, GRID(len), d_prow, d_occ, d_rstart_pad, c->d_pb_rep, nr, len, c->d_pb_lrow);
+        u32 no_rounds = 0;
+#ifdef LZX_DEBUG_KNOBS
+        if (getenv("LZX_PB_NO_ROUNDS")) no_rounds = 1;   // A/B of what the rounds cost
+#endif
+        hipLaunchKernelGGL(k_pb_slots, GRID(len), d_prow, d_occ, d_rstart_pad, c->d_pb_rep, nr, len, c->d_pb_lrow, no_rounds);
         LZX_HIP(hipStreamSynchronize(st));
+#ifdef LZX_DEBUG_KNOBS
+        if (getenv("LZX_PB_STATS")) {   // how often does the gather pass need a later round? (values whose slot an earlier lane of the same instruction holds)
+            std::vector<uint16_t> hs(len);
+            LZX_HIP(hipMemcpy(hs.data(), c->d_pb_lrow, sizeof(uint16_t) * len, hipMemcpyDeviceToHost));
+            u64 late = 0, blocks_late = 0, maxr = 0;
+            for (u64 b0 = 0; b0 < len; b0 += 128) {
+                bool any = false;
+                for (u64 i = b0; i < std::min<u64>(len, b0 + 128); ++i) {
+                    const u32 r = hs[i] >> 10;
+                    if (r) { ++late; any = true; maxr = std::max<u64>(maxr, r); }
+                }
+                blocks_late += any ? 1 : 0;
+            }
+            {   // the first few late values with their neighbourhood: position, slot words around it
+                std::vector<uint16_t> hp(len);
+                LZX_HIP(hipMemcpy(hp.data(), d_prow, sizeof(uint16_t) * len, hipMemcpyDeviceToHost));
+                int shown = 0;
+                for (u64 i = 0; i < len && shown < 6; ++i)
+                    if (hs[i] >> 10) {
+                        u32 R = 0;
+                        while (R + 1 < nr && rstart[R + 1] <= i) ++R;
+                        fprintf(stderr, "[lzx pb stats]   late value at %llu (band %u begins at %u, offset in band %llu, block offset %llu, rep %u): rows",
+                                (unsigned long long)i, R, rstart[R], (unsigned long long)(i - rstart[R]), (unsigned long long)((i - rstart[R]) % 128), rep[R]);
+                        for (u64 j = (i >= 6 ? i - 6 : 0); j < std::min<u64>(len, i + 3); ++j) fprintf(stderr, " %s%u/%u", j == i ? "*" : "", (unsigned)hp[j], (unsigned)(hs[j] >> 10));
+                        fprintf(stderr, "\n");
+                        ++shown;
+                    }
+            }
+            u64 rep1 = 0;
+            for (u32 R = 0; R < nr; ++R) rep1 += rep[R] == 1 ? 1 : 0;
+            fprintf(stderr, "[lzx pb stats] gather slots: %llu values, %llu of them (%.3f %%) in a round > 0 (highest round %llu), %llu of %llu 128-value blocks (%.2f %%) "
+                    "take the slow path; %llu of %u row bands have one slot per row\n", (unsigned long long)len, (unsigned long long)late, 100.0 * late / std::max<double>(1.0, (double)len),
+                    (unsigned long long)maxr, (unsigned long long)blocks_late, (unsigned long long)((len + 127) / 128), 100.0 * blocks_late / std::max<double>(1.0, (double)((len + 127) / 128)),
+                    (unsigned long long)rep1, nr);
+        }
+#endif
     }
 
     // 7. gather items: one per band; a band above 2 targets of values is cut into about target-sized items whose
@@ -1530,8 +1592,10 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
                 ++j;
             }
             out.push_back(items[4 * i]); out.push_back((u32)(j - i)); out.push_back((u32)vals); out.push_back(LZX_PB_ITEM_GROUP);
-            // a group lasts as long as its widest band's wavefront: eight serial batches per Ki values
-            cost.push_back(std::max<u64>(10ull * vals + 24ull * rows, 80ull * widest) + 40000ull);
+            // a group lasts as long as its widest band's wavefront: eight serial batches per Ki values (a group of few bands
+            // gives every band several wavefronts: k_pb_gather)
+            const u64 nbands = j - i, split = nbands <= 1 ? 8 : nbands <= 2 ? 4 : nbands <= 4 ? 2 : 1;
+            cost.push_back(std::max<u64>(10ull * vals + 24ull * rows, 80ull * widest / split) + 40000ull);
             i = j;
         }
         const u32 G = c->pb_gather_grid;
@@ -1700,7 +1764,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         return LZX_OK;
     }
     if (v_ready) LZX_HIP(hipStreamWaitEvent(c->stream, v_ready, 0));   // the staged-columns kernel wrote the v this pass adds into
-    const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 8) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double) +
+    const size_t lds2 = ((size_t)(LZX_PB_GATHER_BLOCK / 64) * (LZX_PB_RB + 64) + LZX_PB_GATHER_BLOCK / 64) * sizeof(double) +
                         16 * (LZX_PB_GATHER_BLOCK / 64) * 8 * sizeof(u32) + 16;   // tiles, wavefront sums, the preloaded item records, the ticket
     // stream loads of the pass as non-temporal loads when the value stream is larger than the caches can hold anyway (k_pb_gather)
     const bool nt = c->pb_gather_nt_opt >= 0 ? c->pb_gather_nt_opt > 0 : 10ull * c->pb_values > LZX_PB_NT_BYTES;

@@ -34,6 +34,10 @@ MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propag
          # ... and the kernel large graphs get: stream loads non-temporal (chosen by the stream's size; forced here)
          dict(propagation_blocking=1, hub_entries=64, pb_target=2048, pb_group_force=4, pb_gather_grid=6, pb_dyn_share=60, pb_gather_nt=1),
          dict(propagation_blocking=1, pb_gather_nt=1),
+         # groups of few small bands: every band streamed by several wavefronts (four with two bands per group, eight for a
+         # group's last single band), folded by its first one behind a barrier
+         dict(propagation_blocking=1, hub_entries=64, pb_group_force=2, pb_target=2048),
+         dict(propagation_blocking=1, hub_entries=256, pb_group_force=3, pb_group=2048, pb_gather_grid=5),
          # the reduced step's cross-lane carry through LDS slots (rounds 1 - 3) instead of the fixed-order scan in registers
          dict(propagation_blocking=1, hub_entries=64, pb_carry_scan=0), dict(propagation_blocking=1, pb_carry_scan=0, pb_target=2048)]
 
