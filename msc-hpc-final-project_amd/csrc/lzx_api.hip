@@ -1134,6 +1134,35 @@ extern "C" int lzx_bench_stream(lzx_handle c, uint64_t bytes, uint32_t reps, dou
     return LZX_OK;
 }
 
+#ifdef LZX_DEBUG_KNOBS
+namespace {
+// which XCD does workgroup b of a launch land on?  (HW_REG_XCC_ID; block -> XCD placement is round-robin from a start that
+// HIP does not promise: MI355X_MICROARCH.md)  A probe for the two process states of DESIGN.md / NOTES 3.1 i.
+__global__ void k_xcc_of_block(u32 *out)
+{
+    if (threadIdx.x == 0) {
+        u32 x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        out[blockIdx.x] = x & 0xfu;
+    }
+}
+}  // namespace
+// debug library only: XCC ids of workgroups 0 .. 15 of `launches` consecutive 16-block launches on the handle's stream
+extern "C" int lzx_dbg_xcc_map(lzx_handle c, uint32_t launches, uint32_t *out /* [launches][16] */)
+{
+    if (!c || !out || launches == 0 || launches > 64) LZX_FAIL(LZX_ERR_ARG, "lzx_dbg_xcc_map: bad argument");
+    LZX_HIP(hipSetDevice(c->device));
+    u32 *d = nullptr;
+    LZX_HIP(hipMalloc(reinterpret_cast<void **>(&d), sizeof(u32) * 16 * launches));
+    for (u32 l = 0; l < launches; ++l) hipLaunchKernelGGL(k_xcc_of_block, dim3(16), dim3(64), 0, c->stream, d + 16 * l);
+    hipError_t e = hipMemcpyAsync(out, d, sizeof(u32) * 16 * launches, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    LZX_HIP(e);
+    return LZX_OK;
+}
+#endif
+
 extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, double *min_ms)
 {
     if (!c || reps == 0 || !avg_ms) LZX_FAIL(LZX_ERR_ARG, "lzx_bench_spmv: bad argument");
