@@ -244,7 +244,16 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           end at 1.2e-6, parallel-final/output/single_double.txt:58-63).  Selects the lazy loop (an error with
  *                           lazy_normalisation = 0 or reorthogonalise).  Default 0.
  *                           SURVEY 8(f) N4.  May be changed between decompositions.
- * These nine are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
+ *   "reference_order"       1: the loop with serial/'s own REDUCTION orders, for a maintainer who wants the device path to
+ *                           reproduce the CPU path's numbers exactly: the SpMV one lane per row of the caller's CSR, entries
+ *                           added in ascending column order (serial/lib/SPMV.cc:24-27 = cu_spMV1, parallel-final/lib/cu_SPMV.cu:31-41),
+ *                           inner product and norm ONE left-to-right accumulator over the caller's vertex order
+ *                           (serial/lib/lanczos.cc:155-171); the elementwise updates as in every mode.  alpha, beta and
+ *                           the basis then equal serial/'s restatement BIT FOR BIT at any k (tests: every fixture, and the
+ *                           1 M- and 10 M-vertex benchmark graphs at k = 50), also together with "reorthogonalise".  A parity
+ *                           instrument, not a fast path (about 70 ms per iteration at 10 M vertices); one rank only.
+ *                           Default 0.  May be changed between decompositions.
+ * These ten are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
  * "phase_mask", "exchange_at_world_1", ...) exist only in liblzx_dbg.so, the same sources built with -DLZX_DEBUG_KNOBS
  * (`make debug`); tools/perf_probe.py and the tests that need them load that library.                               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);

@@ -17,12 +17,12 @@ LIB_PATH = os.path.join(_HERE, "liblzx.so")
 DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
 # what the product library's lzx_set_option knows (include/lzx.h); any other option name selects the debug library
 PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "exchange_fp32",
-                   "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32")
+                   "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32", "reference_order")
 
 # test-only shapes the product library accepts through lzx_test_set_shape (csrc/lzx_test_hooks.h): they select among code
 # paths the product contains (what large graphs get by themselves), so tests that force them still run liblzx.so
 SHAPE_OPTIONS = ("pb_reduce", "pb_target", "pb_unit", "pb_column_band", "pb_run_align", "pb_taper", "pb_dyn_share", "pb_carry_scan", "pb_gather_grid", "pb_gather_nt", "spmv_wgs", "pb_group", "pb_group_force",
-                 "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1", "reference_order", "isolated_rows", "unnormalised_basis", "fuse_staged")
+                 "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1", "isolated_rows", "unnormalised_basis", "fuse_staged")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)

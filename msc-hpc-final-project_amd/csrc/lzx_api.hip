@@ -100,7 +100,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
 {
     if (!c || !name) LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: bad argument");
     // the two options that shape the LOOP, not the graph, may change between decompositions
-    const bool loop_option = !strcmp(name, "reorthogonalise") || !strcmp(name, "basis_fp32");
+    const bool loop_option = !strcmp(name, "reorthogonalise") || !strcmp(name, "basis_fp32") || !strcmp(name, "reference_order");
     if (c->d_row_ptr && !loop_option) LZX_FAIL(LZX_ERR_STATE, "options must be set before the graph is handed over");
     if (loop_option) c->k_prep = 0;   // a decomposition that was being advanced in chunks is abandoned (what it has done stays usable)
     if (!strcmp(name, "hub_entries")) c->hub_opt = value;
@@ -112,6 +112,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "timing_marks_every")) c->marks_every_opt = value;
     else if (!strcmp(name, "reorthogonalise")) c->reorth_opt = value;
     else if (!strcmp(name, "basis_fp32")) c->qf32_opt = value;
+    else if (!strcmp(name, "reference_order")) c->ref_order_opt = value;
 #ifdef LZX_DEBUG_KNOBS
     // experiment knobs and test hooks: only in liblzx_dbg.so (make debug), which tests/ and tools/perf_probe.py load
     // when they ask for one of these; the product library does not know the names
@@ -177,7 +178,6 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "long_row")) c->long_row_opt = value;
     else if (!strcmp(name, "item_len")) c->item_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
-    else if (!strcmp(name, "reference_order")) c->ref_order_opt = value;
     // the lazy loop's two other forms (rows without an edge elementwise instead of one scalar recurrence; q_j stored instead of
     // the unnormalised u_j) and the staged-columns workgroups' place in the shared launch: all compiled into this library
     else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
@@ -306,7 +306,7 @@ static int ensure_capacity(lzx_ctx *c, u32 k, bool qf32)
 static bool loop_is_lazy(const lzx_ctx *c0)
 {
     if (c0->reorth_opt > 0) return false;   // R1 runs the reference's operation order on the normalised basis
-    if (c0->ref_order_opt > 0) return false;   // test shape: the reference's operation AND reduction order
+    if (c0->ref_order_opt > 0) return false;   // option reference_order: the reference's operation AND reduction order
     if (c0->qf32_opt > 0 && c0->lazy_opt != 0) return true;   // the fp32-stored basis lives in the lazy loop: asking for it selects it
     return c0->lazy_opt > 0 || (c0->lazy_opt < 0 && (lzx_exchanges(c0) || c0->codes16));
 }
@@ -366,7 +366,9 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
         if (c->qf32_opt > 0 && (!lazy || c->basis_u_opt == 0))
             LZX_FAIL(LZX_ERR_STATE, "basis_fp32 needs the lazy loop (not with lazy_normalisation = 0, not together with reorthogonalise)");
         if (c->ref_order_opt > 0 && (multi || cs.size() > 1))
-            LZX_FAIL(LZX_ERR_STATE, "the reference_order test shape runs on one rank");
+            LZX_FAIL(LZX_ERR_STATE, "option reference_order runs on one rank");
+        if (c->ref_order_opt > 0 && c->qf32_opt > 0)
+            LZX_FAIL(LZX_ERR_STATE, "option reference_order keeps the fp64 basis (not together with basis_fp32)");
     }
     // From here on the resident basis of an earlier decomposition is gone (its buffers may be reallocated or change form):
     // nothing is resident and nothing prepared until this call has succeeded on every handle -- a failure part-way leaves
@@ -585,7 +587,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
         }
     }
     const u32 reorth = (!lazy && c0->reorth_opt > 0) ? (u32)c0->reorth_opt : 0u;
-    // Test shape reference_order: the three reductions in serial/'s order (lzx_kernels.hip: k_ref_*).  The scalars then
+    // Option reference_order: the three reductions in serial/'s order (lzx_kernels.hip: k_ref_*).  The scalars then
     // arrive in d_scal[0 / 1] the way the several-rank loop's all-reduced ones do, and the vector kernels are the same.
     const bool ref = !lazy && !multi && c0->ref_order_opt > 0;
     const bool scal = multi || ref;   // alpha_j / ||v||^2 come as ONE device scalar each instead of block partials

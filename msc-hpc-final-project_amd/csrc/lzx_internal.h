@@ -258,7 +258,7 @@ struct lzx_ctx {
     // orthogonalised against q_0 .. q_{j-2} (modified Gram-Schmidt, the reference's order) before alpha_j is taken; the
     // reference hard-codes e = 2.  0 / -1: off.  Runs the reference-order loop (normalised basis, every row elementwise).
     int64_t reorth_opt = -1;
-    // Test shape reference_order (lzx_test_set_shape; one rank): SpMV one lane per row of the caller's CSR, inner product and
+    // Option reference_order (one rank): SpMV one lane per row of the caller's CSR, inner product and
     // norm one left-to-right accumulator in the caller's vertex order -- the reduction orders serial/ fixes (SPMV.cc:24-27,
     // lanczos.cc:155-171), so alpha / beta / Q meet the oracle's bit for bit at any k.  A parity instrument, not a fast path.
     int64_t ref_order_opt = -1;

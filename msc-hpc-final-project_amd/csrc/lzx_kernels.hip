@@ -447,7 +447,7 @@ __global__ void k_widen_col(const float *in, double *out, u32 n)
 }
 
 // --------------------------------------------------------------------------------------------------
-// Reference-order test shape (lzx_test_set_shape "reference_order"; one rank): the loop's three reductions in the order
+// Option "reference_order" (include/lzx.h; one rank): the loop's three reductions in the order
 // serial/ fixes, so that alpha, beta and the basis can be compared with it BIT FOR BIT at any k.  Not a fast path: a parity
 // instrument, run by tests only.
 //   k_ref_spmv      one lane per row of the caller's CSR, entries added one at a time in ascending column order starting from

@@ -5,10 +5,7 @@
 // "pb_dyn_share" (per cent of the gather pass left to its dynamic tail; 0 = every item dealt by the host), "pb_gather_grid" (at most this many gather workgroups),
 // "pb_gather_nt" (the gather pass's stream loads non-temporal 1 / cached 0, whatever the stream's size),
 // "pb_group" / "pb_group_force" (small row bands gathered one wavefront each), "narrow_slices", "tie_sort", "long_row",
-// "item_len", "exchange_at_world_1" (a 1-rank RCCL communicator runs the several-rank loop, collectives included), and
-// "reference_order" (one rank: the SpMV one lane per row of the caller's CSR, inner product and norm one left-to-right
-// accumulator over the caller's vertex order -- the reduction orders of serial/lib/SPMV.cc:24-27 and lanczos.cc:155-171, so
-// that alpha, beta and Q equal the oracle's restatement of serial/ bit for bit at any k; a parity instrument, slow),
+// "item_len", "exchange_at_world_1" (a 1-rank RCCL communicator runs the several-rank loop, collectives included),
 // "pb_carry_scan" (reduced steps: a row that spans lanes summed by the fixed-order cross-lane scan 1 / through LDS carry slots 0),
 // "isolated_rows" (0: rows without an edge updated elementwise instead of as one scalar recurrence), "unnormalised_basis" (0: the
 // resident basis holds q_j instead of u_j), "fuse_staged" (0: staged-columns kernel in a launch of its own; 1: behind the

@@ -65,11 +65,16 @@ struct lanczosTimings {
 //                  a finished decomposition (parallel-final/lib/multiplyOut.cu:25-49; writeup section 11); here convergence
 //                  saves SpMVs.  get_krylov() is the dimension actually used afterwards.
 //   basis_fp32     the device-resident basis stored as fp32 (half the HBM; alpha / beta unchanged bit for bit).
+//   reference_order  device path: the loop with the CPU path's own reduction orders (SpMV one lane per row, inner product and
+//                  norm one left-to-right accumulator: serial/lib/SPMV.cc:24-27, lanczos.cc:155-171), so that
+//                  lanczosDecomp(A, k, x, true, {reference_order}) and lanczosDecomp(A, k, x, false) hold the same alpha, beta
+//                  and Q BIT FOR BIT -- a parity instrument (slow), one GPU handle only.
 struct lanczosOptions {
   unsigned arnoldi_every = 0;
   unsigned adaptive_step = 0;
   double adaptive_tol = 1e-10;
   bool basis_fp32 = false;
+  bool reference_order = false;
 };
 
 struct convergenceReport {

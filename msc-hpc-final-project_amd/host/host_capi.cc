@@ -151,6 +151,43 @@ long host_expm_options_file(const char *path, unsigned k, int cuda, int device_m
   }
 }
 
+// Drop-in parity, literally: the same graph file through lanczosDecomp(A, k, x, /*cuda*/false) and through
+// lanczosDecomp(A, k, x, /*cuda*/true, {reference_order}); returns 1 when alpha, beta and every entry of Q are bit-identical,
+// 0 when they are not (first difference in diff[0..2]: 0 alpha / 1 beta / 2 Q, index, -), < 0 on error.
+long host_reference_order_check(const char *path, unsigned k, double *alpha_dev, double *alpha_cpu, unsigned *diff) {
+  try {
+    std::ifstream fs(path);
+    if (fs.fail()) { g_host_err = std::string("cannot open ") + path; return -1; }
+    unsigned n = 0, edges = 0;
+    fs >> n >> n >> edges;
+    adjMatrix A(n, edges, fs);
+    std::vector<double> x(n, 1.0);
+    lanczosDecomp<double> C(A, k, x.data(), false);
+    lanczosOptions o;
+    o.reference_order = true;
+    lanczosDecomp<double> D(A, k, x.data(), true, o);
+    if (alpha_dev) std::copy(D.get_alpha(), D.get_alpha() + k, alpha_dev);
+    if (alpha_cpu) std::copy(C.get_alpha(), C.get_alpha() + k, alpha_cpu);
+    for (unsigned j = 0; j < k; ++j)
+      if (std::memcmp(D.get_alpha() + j, C.get_alpha() + j, sizeof(double)) != 0) { if (diff) { diff[0] = 0; diff[1] = j; } return 0; }
+    for (unsigned j = 0; j + 1 < k; ++j)
+      if (std::memcmp(D.get_beta() + j, C.get_beta() + j, sizeof(double)) != 0) { if (diff) { diff[0] = 1; diff[1] = j; } return 0; }
+    // the bases: the CPU path stores Q row-major (serial/lib/lanczos.cc:47-48), the device path as k contiguous vectors
+    const double *qd = D.basis();
+    const double *qc = C.basis();
+    for (unsigned j = 0; j < k; ++j)
+      for (unsigned r = 0; r < n; ++r)
+        if (std::memcmp(qd + static_cast<std::size_t>(j) * n + r, qc + j + static_cast<std::size_t>(r) * k, sizeof(double)) != 0) {
+          if (diff) { diff[0] = 2; diff[1] = j; diff[2] = r; }
+          return 0;
+        }
+    return 1;
+  } catch (const std::exception &e) {
+    g_host_err = e.what();
+    return -3;
+  }
+}
+
 // Loader only: CSR of a graph file as the adjMatrix file constructor builds it.
 // row_offset[n+1], col_idx[2*E] (caller sizes them from the header); returns stored edges or < 0.
 long host_load_csr(const char *path, unsigned *row_offset, unsigned *col_idx, unsigned max_nnz) {

@@ -142,6 +142,7 @@ void lanczosDecomp<T>::cu_decompose() {
   for (int p = 0; p < world; ++p) {   // loop options: may change between decompositions on the resident graph
     lzx_or_throw(lzx_set_option(hs[p], "reorthogonalise", opts.arnoldi_every), "lzx_set_option(reorthogonalise)");
     lzx_or_throw(lzx_set_option(hs[p], "basis_fp32", opts.basis_fp32 ? 1 : 0), "lzx_set_option(basis_fp32)");
+    lzx_or_throw(lzx_set_option(hs[p], "reference_order", opts.reference_order ? 1 : 0), "lzx_set_option(reference_order)");
   }
   lzx_stats st{};
   auto run = [&](const double *x0, double *a, double *b) {

@@ -103,6 +103,7 @@ int main(int argc, char **argv) {
   if (const char *v = std::getenv("FINAL_ARNOLDI")) host_opt.arnoldi_every = dev_opt.arnoldi_every = static_cast<unsigned>(std::atoi(v));
   if (const char *v = std::getenv("FINAL_ADAPTIVE_STEP")) dev_opt.adaptive_step = static_cast<unsigned>(std::atoi(v));
   if (const char *v = std::getenv("FINAL_ADAPTIVE_TOL")) dev_opt.adaptive_tol = std::atof(v);
+  dev_opt.reference_order = env_on("FINAL_REFERENCE_ORDER");   // the device run with the CPU run's reduction orders: identical alpha / beta / Q
 
   // ---- CPU ----
   double cpu_lanczos = 0, cpu_mult = 0, cpu_whole = 0;

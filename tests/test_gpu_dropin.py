@@ -249,3 +249,36 @@ def test_adaptive_stop_through_the_classes_and_the_cli(pkg, oracle, tmp_path):
     assert out.returncode == 0, out.stderr
     line = [l for l in out.stdout.splitlines() if l.startswith("adaptive run: k_used")]
     assert line and f"k_used = {k_used} of at most {kmax}" in line[0] and "converged" in line[0], out.stdout[-1500:]
+
+
+def test_reference_order_through_the_classes(pkg, oracle, tmp_path):
+    """Drop-in parity, literally: the same graph file through `lanczosDecomp(A, k, x, /*cuda*/false)` -- the class layer's CPU
+    path, serial/lib/lanczos.cc:9-56 restated -- and through `lanczosDecomp(A, k, x, true, {reference_order})`, the device
+    path with serial/'s reduction orders: alpha, beta and every entry of Q bit-identical (the C shim compares them with
+    memcmp).  And the default device path on the same file: the same alpha_0, not the same bits."""
+    import ctypes
+    import subprocess
+    O = oracle
+    H = ctypes.CDLL(os.path.join(ROOT, "msc-hpc-final-project_amd", "host", "libmschpc_host.so"))
+    H.host_reference_order_check.restype = ctypes.c_long
+    H.host_reference_order_check.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_uint)]
+    H.host_last_error.restype = ctypes.c_char_p
+    for name, (rp, ci) in (("er", O.gen_er(6000, 40000, 9)), ("rmat", O.gen_rmat(14, 12000, 150000, 5))):
+        n = len(rp) - 1
+        mtx = str(tmp_path / f"{name}.mtx")
+        O.write_mtx(mtx, n, rp, ci)
+        k = 24
+        a_dev, a_cpu = np.zeros(k), np.zeros(k)
+        diff = (ctypes.c_uint * 3)()
+        rc = H.host_reference_order_check(mtx.encode(), k, a_dev.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                          a_cpu.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), diff)
+        assert rc == 1, (name, rc, list(diff), H.host_last_error())
+        assert np.array_equal(a_dev, a_cpu)
+        a_ref, _, _, _ = O.lanczos(rp, ci, k, np.ones(n), want_q=False)
+        assert np.array_equal(a_cpu, a_ref), name          # ... and both are the oracle's
+    # the CLI: FINAL_REFERENCE_ORDER=1 makes `final`'s device run reproduce its serial run (relative error of the answers: 0)
+    exe = os.path.join(ROOT, "msc-hpc-final-project_amd", "host", "final")
+    out = subprocess.run([exe, "-n", "3000", "-e", "20000", "-k", "12"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, FINAL_REFERENCE_ORDER="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -34,7 +34,7 @@ def _protocol(O, eng, rp, ci, n, k, name, small_ks, want_q):
     say("engine")
     a, b, Q, xn, st = eng.lanczos(x0, k, want_q=want_q)
     assert xn == xn_ref and st["iters"] == k and np.isfinite(a).all() and np.isfinite(b).all()
-    # the same graph through the product library's `reference_order` test shape -- SpMV one lane
+    # the same graph with the product library's option `reference_order` -- SpMV one lane
     # per row of the caller's CSR, inner product / norm one left-to-right accumulator (serial/lib/SPMV.cc:24-27,
     # lanczos.cc:155-171).  With serial/'s reduction order the device loop must reproduce the oracle's restatement of serial/
     # BIT FOR BIT at BASELINE's k = 50: all 50 alpha, all 49 beta, every entry of the basis.  So "within 1e-10 of serial/" holds
