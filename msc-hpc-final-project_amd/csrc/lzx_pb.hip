@@ -820,8 +820,6 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
 #endif
                 __builtin_amdgcn_wave_barrier();
                 GSTAMP(t_stream);
-                __builtin_amdgcn_wave_barrier();
-                GSTAMP(t_stream);
             }
             if (r_split > 1u) __syncthreads();   // (wave-uniform per item: every wavefront of the workgroup passes here) the partner tiles are complete
             if (r_live && part == 0u) {
