@@ -193,6 +193,30 @@ def test_bench_rehearses_the_multi_gpu_flow():
     assert j["value"] > 0 and j["config"]["lanczos_coefficients_finite"]
 
 
+def test_bench_watchdog_makes_a_hung_trial_visible():
+    """a collective that never completes in bench.py's overlapped-exchange trial must show in the
+    RETURN CODE.  Rehearsed on the one-GPU box with a trial limit no trial can meet (1 ms): the watchdog prints the line it
+    holds -- the single all-gather measurement, marked "did not finish" -- and ends the rank with EXIT_TRIAL_HUNG, so the
+    launcher reports failure; the held line is still a complete, valid JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c2",
+           "--steps", "10", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, LZX_BENCH_REHEARSE_MULTI="1", LZX_BENCH_TRIAL_LIMIT_S="0.001"))
+    assert out.returncode != 0, out.stdout[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stderr[-3000:]
+    j = json.loads(lines[-1])
+    assert j["value"] > 0 and j["steps"] == 10 and j["config"]["k"] == 50
+    assert "did not finish" in j["config"]["exchange_tuning_ms_per_iter"]["overlapped"]
+    assert "did not finish within" in out.stderr
+
+
 def test_adaptive_stop_through_the_classes_and_the_cli(pkg, oracle, tmp_path):
     """N3 proper in the drop-in layer: lanczosDecomp(A, k_max, x, cuda = true, lanczosOptions{adaptive_step, adaptive_tol})
     advances the device decomposition in chunks and stops when the answer has converged -- fewer SpMVs than k_max, the
