@@ -644,8 +644,13 @@ int lzx_graph_prepare(lzx_ctx *c)
 
     // ---- 3. host: split rows / slices (local rows are sorted by degree, descending) ----
     // blocked mode: the tables hold staged columns only and a lane's packets come from LDS-only sums, so wider slices
-    // cost less than more split-row items (C3 staged-column kernel 0.127 -> 0.118 ms from 128 to 256; 512+ loses again)
-    const u32 long_thr = c->long_row_opt > 0 ? (u32)c->long_row_opt : (pb ? 2 * LZX_LONG_ROW : LZX_LONG_ROW);
+    // cost less than more split-row items: 256 staged entries per row -- and 1024 where a wavefront has many slices to
+    // even out the long ones (from 2 Mi rows with an edge per rank).  Round 4, parity-controlled A/B (every configuration in
+    // both process states, profiles/r4_long_row.txt): 10 M vertices 0.572 -> 0.556 ms per SpMV (768: 0.551; 512 and
+    // 1536: - 1 %), 4 M vertices 0.213 -> 0.206; the 1 M-vertex graph (2.5 slices per wavefront) LOSES with wider slices
+    // (512: + 4 %, 1024: + 42 %: a wavefront's one long slice is the launch's tail), hence the size rule.
+    const u32 long_thr = c->long_row_opt > 0 ? (u32)c->long_row_opt
+                         : (pb ? (c->rows_live >= (1u << 21) ? 8 * LZX_LONG_ROW : 2 * LZX_LONG_ROW) : LZX_LONG_ROW);
     u32 n_long = 0;
     for (u32 l = 0; l < c->n_loc_real; ++l)
         if (degl[l] > long_thr) n_long = l + 1;
