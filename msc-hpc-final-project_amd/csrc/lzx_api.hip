@@ -168,6 +168,7 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_taper")) c->pb_taper_opt = value;
     else if (!strcmp(name, "pb_dyn_share")) c->pb_dyn_opt = value;
     else if (!strcmp(name, "pb_carry_scan")) c->pb_scan_opt = value;
+    else if (!strcmp(name, "pb_scatter_nt")) c->pb_scatter_nt_opt = value;
     else if (!strcmp(name, "pb_gather_grid")) c->pb_grid_cap_opt = value;
     else if (!strcmp(name, "pb_gather_nt")) c->pb_gather_nt_opt = value;
     else if (!strcmp(name, "spmv_wgs")) c->spmv_wgs_opt = value;

@@ -69,6 +69,7 @@ static constexpr u64 LZX_PB_SLOT_LIMIT = (1ull << 32) - (1ull << 24);
 // reduced runs (partial row sums instead of single values cross the two passes)
 static constexpr u32 LZX_PBR_STEP = 512;      // entries per wavefront step; reduced runs are padded to whole steps
 static constexpr u32 LZX_PBR_MIN_RUN = 384;   // a (row band, column band) run of at least this many entries is reduced
+static constexpr bool LZX_PB_SCATTER_NT = true;   // the scatter pass's code / slot tables as non-temporal loads on large, mostly reduced value streams (test shape pb_scatter_nt)
 static constexpr bool LZX_PB_CARRY_SCAN = true;   // reduced steps: rows that span lanes are summed by a cross-lane scan in registers (fixed order); false: LDS carry slots
 
 struct lzx_ctx {
@@ -223,6 +224,7 @@ struct lzx_ctx {
     int64_t spmv_wgs_opt = -1;         // test shape spmv_wgs: at most this many workgroups of k_spmv / staged-columns workgroups of the shared launch
     int64_t pb_gather_nt_opt = -1;     // test shape pb_gather_nt: the gather pass's stream loads non-temporal (1) or cached (0); -1: by the stream's size
     int64_t pb_grid_cap_opt = -1;      // test shape pb_gather_grid: at most this many gather workgroups
+    int64_t pb_scatter_nt_opt = -1;    // test shape pb_scatter_nt: the scatter pass's table loads non-temporal (1) / cached (0); -1: LZX_PB_SCATTER_NT by size
     int64_t pb_scan_opt = -1;          // test shape pb_carry_scan: 1 = cross-lane scan in registers, 0 = LDS carry slots, -1 = LZX_PB_CARRY_SCAN
     int64_t pb_dyn_opt = -1;           // test shape pb_dyn_share: per cent of the gather pass's cost left to the dynamic tail (-1: default)
     u64 pb_values = 0;                 // values the scatter passes hand to the gather pass per SpMV (incl. padding)

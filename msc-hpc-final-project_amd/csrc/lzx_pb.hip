@@ -385,10 +385,28 @@ __device__ __forceinline__ double pbr_carry_scan(double tail, bool has)
     return dpp_f64<0x138, 0xf>(P);   // wave_shr:1: lane L takes lane L - 1's prefix (lane 0: nothing before it)
 }
 
+// the scatter pass's table loads (codes, value slots): each is read exactly once per SpMV.  NTC: as non-temporal loads, so that
+// they do not take Infinity-Cache room from the values the pass is writing (which the gather pass then finds there)
+template <bool NTC> __device__ __forceinline__ uint4 sld(const uint4 *p)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    if (!NTC) return *p;
+    const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+template <bool NTC> __device__ __forceinline__ uint2 sld(const uint2 *p)
+{
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    if (!NTC) return *p;
+    const u2v t = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(p));
+    return make_uint2(t.x, t.y);
+}
+template <bool NTC> __device__ __forceinline__ u32 sld(const u32 *p) { return NTC ? __builtin_nontemporal_load(p) : *p; }
+
 // SCAN: a row that spans lanes is summed across them by pbr_carry_scan (registers only, order fixed by the program);
 // otherwise through wave-private LDS carry slots (the round-1 .. 3 form: one ds_add_f64 per lane, whose same-slot lanes the
 // LDS unit orders).
-template <u32 CB, bool SCAN>
+template <u32 CB, bool SCAN, bool NTC>
 __device__ __forceinline__ void
 pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
                 const double *__restrict__ x, u64 xlen, double *val, const u32 ublock)
@@ -472,7 +490,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
             u32 b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                c[u] = sld<NTC>(scode + (size_t)(s + u * W) * 64 + lane);
                 b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
             }
 #pragma unroll
@@ -484,7 +502,7 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 if (s + u * W < end) {
-                    c[u] = scode[(size_t)(s + u * W) * 64 + lane];
+                    c[u] = sld<NTC>(scode + (size_t)(s + u * W) * 64 + lane);
                     b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
                 }
             }
@@ -506,8 +524,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
             u32 d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                c[u] = q_lcol[j + u * 64];
-                d[u] = q_dst[j + u * 64];
+                c[u] = sld<NTC>(q_lcol + j + u * 64);
+                d[u] = sld<NTC>(q_dst + j + u * 64);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -527,8 +545,8 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const u32 jj = j + u * 64 < wend ? j + u * 64 : blk;     // clamped: unconditional loads
-                c[u] = q_lcol[jj];
-                d[u] = q_dst[jj];
+                c[u] = sld<NTC>(q_lcol + jj);
+                d[u] = sld<NTC>(q_dst + jj);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -548,12 +566,12 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
     }
 }
 
-template <u32 CB, bool SCAN>
+template <u32 CB, bool SCAN, bool NTC>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
              const double *__restrict__ x, u64 xlen, double *val)
 {
-    pb_scatter_body<CB, SCAN>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
+    pb_scatter_body<CB, SCAN, NTC>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
 }
 
 // Scatter pass and staged-columns kernel in ONE launch (single GPU, 16 Ki bands): the persistent workgroups of the
@@ -563,7 +581,7 @@ k_pb_scatter(const u32 *unit, const uint4 *scode, const u32 *sbase, const uint2 
 // the launch ends with the small tapered units instead of a second ramp and drain; the other order (debug knob
 // fuse_staged = 1: staged columns behind the units, filling the scatter pass's tail while the write-back of its values
 // drains in their shadow) measures the same.  C3: SpMV 0.616 -> 0.601 ms against separate launches.
-template <u32 CB, bool SCAN>
+template <u32 CB, bool SCAN, bool NTC>
 __global__ void __launch_bounds__(1024)
 k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *sbase, const uint2 *q_lcol, const u32 *q_dst,
                   const double *__restrict__ x, u64 xlen, double *val, const SpmvArgs a, const u32 spmv_first)
@@ -571,10 +589,10 @@ k_pb_scatter_spmv(const u32 *unit, u32 n_units, const uint4 *scode, const u32 *s
     const u32 spmv_blocks = gridDim.x - n_units;
     if (spmv_first) {
         if (blockIdx.x < spmv_blocks) spmv_body<2, false>(a, blockIdx.x, spmv_blocks);
-        else pb_scatter_body<CB, SCAN>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x - spmv_blocks);
+        else pb_scatter_body<CB, SCAN, NTC>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x - spmv_blocks);
         return;
     }
-    if (blockIdx.x < n_units) pb_scatter_body<CB, SCAN>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
+    if (blockIdx.x < n_units) pb_scatter_body<CB, SCAN, NTC>(unit, scode, sbase, q_lcol, q_dst, x, xlen, val, blockIdx.x);
     else spmv_body<2, false>(a, blockIdx.x - n_units, spmv_blocks);
 }
 
@@ -1724,8 +1742,22 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     // through LDS carry slots (0)
     const bool scan = c->pb_scan_opt >= 0 ? c->pb_scan_opt > 0 : LZX_PB_CARRY_SCAN;
     const size_t lds1 = ((size_t)c->pb_cb + 2 + (scan ? 0 : 16 * 66)) * sizeof(double);
-    auto kern = c->pb_cb == 8192 ? (scan ? k_pb_scatter<8192, true> : k_pb_scatter<8192, false>)
-                                 : (scan ? k_pb_scatter<LZX_PB_CB, true> : k_pb_scatter<LZX_PB_CB, false>);
+    // the pass's tables as non-temporal loads (test shape pb_scatter_nt).  Default: when the value stream is larger than the caches
+    // and most entries sit in reduced runs -- there the tables are the larger stream and streaming them past the Infinity Cache
+    // leaves more of the freshly written values for the gather (10 M-vertex R-MAT -1.2 %, 4 M -4.3 %); where the values are the
+    // larger stream (Erdos-Renyi: almost no reduced runs) it measured +1.3 % (profiles/r4_knob_sweeps.txt)
+    const bool ntc = c->pb_scatter_nt_opt >= 0 ? c->pb_scatter_nt_opt > 0
+                                               : (LZX_PB_SCATTER_NT && 10ull * c->pb_values > LZX_PB_NT_BYTES && 2 * c->pbr_entries > c->pb_entries);
+    using scatter_fn = void (*)(const u32 *, const uint4 *, const u32 *, const uint2 *, const u32 *, const double *, u64, double *);
+    auto pick_scatter = [&]() -> scatter_fn {
+        if (c->pb_cb == 8192) {
+            if (scan) return ntc ? k_pb_scatter<8192, true, true> : k_pb_scatter<8192, true, false>;
+            return ntc ? k_pb_scatter<8192, false, true> : k_pb_scatter<8192, false, false>;
+        }
+        if (scan) return ntc ? k_pb_scatter<LZX_PB_CB, true, true> : k_pb_scatter<LZX_PB_CB, true, false>;
+        return ntc ? k_pb_scatter<LZX_PB_CB, false, true> : k_pb_scatter<LZX_PB_CB, false, false>;
+    };
+    scatter_fn kern = pick_scatter();
     if (c->pb_units)
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     // one workgroup per unit / static item lists (k_pb_scatter, k_pb_gather); persistent and ticketed forms were measured in
@@ -1734,8 +1766,15 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         if (u1 <= u0 && !(may_fuse && fuse && fused)) return;
         if (may_fuse && fuse && fused && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192) && u0 == 0) {
             // the staged-columns workgroups share the launch of the scatter units (k_pb_scatter_spmv)
-            auto kf = c->pb_cb == 8192 ? (scan ? k_pb_scatter_spmv<8192, true> : k_pb_scatter_spmv<8192, false>)
-                                       : (scan ? k_pb_scatter_spmv<LZX_PB_CB, true> : k_pb_scatter_spmv<LZX_PB_CB, false>);
+            using fused_fn = void (*)(const u32 *, u32, const uint4 *, const u32 *, const uint2 *, const u32 *, const double *, u64, double *, const SpmvArgs, const u32);
+            fused_fn kf;
+            if (c->pb_cb == 8192) {
+                if (scan) kf = ntc ? k_pb_scatter_spmv<8192, true, true> : k_pb_scatter_spmv<8192, true, false>;
+                else kf = ntc ? k_pb_scatter_spmv<8192, false, true> : k_pb_scatter_spmv<8192, false, false>;
+            } else {
+                if (scan) kf = ntc ? k_pb_scatter_spmv<LZX_PB_CB, true, true> : k_pb_scatter_spmv<LZX_PB_CB, true, false>;
+                else kf = ntc ? k_pb_scatter_spmv<LZX_PB_CB, false, true> : k_pb_scatter_spmv<LZX_PB_CB, false, false>;
+            }
             const size_t ldsf = std::max(lds1, c->spmv_lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             hipLaunchKernelGGL(kf, dim3(u1 + fuse_blocks), dim3(1024), ldsf, c->stream, c->d_pb_unit, u1, c->d_pbr_code, c->d_pbr_base,

@@ -39,7 +39,9 @@ MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propag
          dict(propagation_blocking=1, hub_entries=64, pb_group_force=2, pb_target=2048),
          dict(propagation_blocking=1, hub_entries=256, pb_group_force=3, pb_group=2048, pb_gather_grid=5),
          # the reduced step's cross-lane carry through LDS slots (rounds 1 - 3) instead of the fixed-order scan in registers
-         dict(propagation_blocking=1, hub_entries=64, pb_carry_scan=0), dict(propagation_blocking=1, pb_carry_scan=0, pb_target=2048)]
+         dict(propagation_blocking=1, hub_entries=64, pb_carry_scan=0), dict(propagation_blocking=1, pb_carry_scan=0, pb_target=2048),
+         # the scatter pass's tables read with non-temporal loads
+         dict(propagation_blocking=1, hub_entries=64, pb_scatter_nt=1)]
 
 
 def graphs(O):
