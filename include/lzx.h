@@ -107,6 +107,17 @@ const char *lzx_last_error(void);
 int lzx_comm_unique_id(uint8_t id[128]);
 int lzx_comm_init_rank(lzx_handle h, const uint8_t id[128], int rank, int world);
 int lzx_comm_init_local(lzx_handle *hs, int world);
+/*   lzx_comm_ipc_export / lzx_comm_ipc_init : one process per rank WITHOUT a collective library ("peer windows"): every
+ *       rank's receive buffers are mapped into its peers (HIP inter-process memory handles), each rank's own kernel
+ *       pushes its slice straight into them -- over xGMI point to point between GPUs, the access pattern
+ *       parallel-two-cards/lib/cu_lanczos.cu:62-67 enables with cudaDeviceEnablePeerAccess -- and the iteration's two
+ *       scalars travel through mailboxes in device memory (the host round trips of cu_lanczos.cu:104-105,119-120 gone).
+ *       Ranks may share a GPU.  Every rank calls export (LZX_IPC_BLOB bytes out), the caller gathers the `world` blobs
+ *       in rank order over any side channel, every rank calls init with the whole list.  A peer that does not arrive
+ *       within LZX_IPC_TIMEOUT_MS (environment, default 20000) makes the call in progress fail with LZX_ERR_COMM.     */
+#define LZX_IPC_BLOB 128
+int lzx_comm_ipc_export(lzx_handle h, uint8_t blob[LZX_IPC_BLOB]);
+int lzx_comm_ipc_init(lzx_handle h, const uint8_t *blobs /* [world][LZX_IPC_BLOB] */, int rank, int world);
 
 /* ---- graph hand-over ---------------------------------------------------------------------------
  * lzx_set_graph_csr: upload of IA/JA, parallel-final/lib/cu_lanczos.cu:88-94 (`row_offset[n+1]`,

@@ -63,6 +63,8 @@ SYMBOLS = [
     ("lzx_comm_unique_id", ctypes.c_int, [_u8p]),
     ("lzx_comm_init_rank", ctypes.c_int, [_h, _u8p, ctypes.c_int, ctypes.c_int]),
     ("lzx_comm_init_local", ctypes.c_int, [_hp, ctypes.c_int]),
+    ("lzx_comm_ipc_export", ctypes.c_int, [_h, _u8p]),
+    ("lzx_comm_ipc_init", ctypes.c_int, [_h, _u8p, ctypes.c_int, ctypes.c_int]),
     ("lzx_set_graph_csr", ctypes.c_int, [_h, ctypes.c_uint64, ctypes.c_uint64, _u64p, _u32p]),
     ("lzx_set_graph_csr32", ctypes.c_int, [_h, ctypes.c_uint32, ctypes.c_uint32, _u32p, _u32p]),
     ("lzx_set_graph_edges", ctypes.c_int, [_h, ctypes.c_uint64, ctypes.c_uint64, _u32p, _u32p]),
@@ -205,6 +207,20 @@ class Engine:
     def comm_init_rank(self, uid: np.ndarray, rank: int, world: int):
         uid = np.ascontiguousarray(uid, dtype=np.uint8)
         _check(self.L.lzx_comm_init_rank(self.h, _p(uid, _u8p), rank, world), "lzx_comm_init_rank", self.L)
+
+    IPC_BLOB = 128   # LZX_IPC_BLOB
+
+    def comm_ipc_export(self) -> np.ndarray:
+        """This rank's window for the peer-window transport (include/lzx.h): 128 bytes to be gathered from all ranks."""
+        blob = np.zeros(self.IPC_BLOB, dtype=np.uint8)
+        _check(self.L.lzx_comm_ipc_export(self.h, _p(blob, _u8p)), "lzx_comm_ipc_export", self.L)
+        return blob
+
+    def comm_ipc_init(self, blobs: np.ndarray, rank: int, world: int):
+        blobs = np.ascontiguousarray(blobs, dtype=np.uint8).reshape(-1)
+        if blobs.size != world * self.IPC_BLOB:
+            raise ValueError(f"comm_ipc_init: {world} ranks need {world * self.IPC_BLOB} bytes of exports, got {blobs.size}")
+        _check(self.L.lzx_comm_ipc_init(self.h, _p(blobs, _u8p), rank, world), "lzx_comm_ipc_init", self.L)
 
     # ---- graph ----
     def set_graph_csr(self, row_ptr, col_idx):

@@ -252,6 +252,7 @@ static int sync_all(std::vector<lzx_ctx *> &cs)
         LZX_HIP(hipSetDevice(c->device));
         LZX_HIP(hipStreamSynchronize(c->stream));
         LZX_HIP(hipStreamSynchronize(c->stream2));
+        LZX_TRY(lzx_comm_ipc_check(c));   // peer windows: a peer that never arrived ended a wait at its deadline
     }
     return LZX_OK;
 }
@@ -559,27 +560,27 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
             dst[i] = cs[i]->d_xbuf;
         }
         if (!overlap) {
-            if (c0->xfp32) LZX_TRY(lzx_comm_allgather_fp32(cs, src.data()));   // N4: the same prefix, rounded to fp32 on the wire
+            if (c0->xfp32) LZX_TRY(lzx_comm_allgather_fp32(cs, src.data(), true));   // N4: the same prefix, rounded to fp32 on the wire
             else
-            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs));   // only the prefix that has edges
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs, false, true));   // only the prefix that has edges
             LZX_HIP(hipSetDevice(c0->device));
             LZX_TRY(mk.tick(CAT_COMM));
         } else {
             LZX_TRY(lzx_comm_order(cs, /*from main*/ false, /*to exchange*/ true));
-            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs0, true));
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs0, true, true));
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
                 LZX_HIP(hipEventRecord(c->ev_c0, c->stream2));
             }
             if (c0->sparse) {   // every peer gets only what its rows reference
                 for (size_t i = 0; i < cs.size(); ++i) src[i] = next_u(cs[i]);
-                LZX_TRY(lzx_comm_sparse_chunk1(cs, src.data()));
+                LZX_TRY(lzx_comm_sparse_chunk1(cs, src.data(), true));
             } else {
                 for (size_t i = 0; i < cs.size(); ++i) {
                     src[i] = next_u(cs[i]) + cs[i]->xs0;
                     dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
                 }
-                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
+                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true, true));
             }
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
@@ -698,9 +699,9 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
                 src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
                 dst[i] = cs[i]->d_xbuf;
             }
-            if (c0->xfp32) LZX_TRY(lzx_comm_allgather_fp32(cs, src.data()));
+            if (c0->xfp32) LZX_TRY(lzx_comm_allgather_fp32(cs, src.data(), true));
             else
-            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs));   // only the prefix that has edges
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs, false, true));   // only the prefix that has edges
             LZX_HIP(hipSetDevice(c0->device));
             LZX_TRY(mk.tick(CAT_COMM));
         }
@@ -712,20 +713,20 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
                 src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
                 dst[i] = cs[i]->d_xbuf;
             }
-            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs0, true));
+            LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs0, true, true));
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));
                 LZX_HIP(hipEventRecord(c->ev_c0, c->stream2));
             }
             if (c0->sparse) {
                 for (size_t i = 0; i < cs.size(); ++i) src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq;
-                LZX_TRY(lzx_comm_sparse_chunk1(cs, src.data()));
+                LZX_TRY(lzx_comm_sparse_chunk1(cs, src.data(), true));
             } else {
                 for (size_t i = 0; i < cs.size(); ++i) {
                     src[i] = cs[i]->d_Q + (size_t)(j + 1) * cs[i]->ldq + cs[i]->xs0;
                     dst[i] = cs[i]->d_xbuf + (size_t)cs[i]->world * cs[i]->xs0;
                 }
-                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true));
+                LZX_TRY(lzx_comm_allgather(cs, src.data(), dst.data(), c0->xs - c0->xs0, true, true));
             }
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));

@@ -7,6 +7,8 @@
 //     machine without RCCL and shares the copy a host program (e.g. PyTorch) may already have loaded.
 //   * local (all handles in one process -- the reference's two-cards model generalised,
 //     parallel-two-cards/lib/cu_lanczos.cu:125,158): device-to-device copies ordered by events.
+//   * peer windows (one process per rank, lzx_ipc.hip): buffers mapped across processes, data pushed by the sender's
+//     kernel, ordering by sequence numbers in device memory; dispatched from the same operations below.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -117,6 +119,7 @@ extern "C" int lzx_comm_init_rank(lzx_handle c, const uint8_t id[128], int rank,
 int lzx_comm_agree(lzx_ctx *c, bool ok, bool *all_ok)
 {
     *all_ok = ok;
+    if (c->comm_kind == 3) return lzx_comm_ipc_agree(c, ok, all_ok);
     if (c->comm_kind != 2 || !c->nccl_comm) return LZX_OK;
     double v = ok ? 1.0 : 0.0;
     LZX_HIP(hipSetDevice(c->device));
@@ -184,6 +187,7 @@ void lzx_comm_release(lzx_ctx *c)
         (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
     }
     c->nccl_comm = c->nccl_comm2 = nullptr;
+    lzx_comm_ipc_release(c);
     if (c->d_mail) (void)hipFree(c->d_mail);
     c->d_mail = nullptr;
     c->mail_ok = false;
@@ -260,6 +264,7 @@ int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count)
                                   static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
         return LZX_OK;
     }
+    if (c0->comm_kind == 3) return lzx_comm_ipc_allreduce(c0, slot, count, 0);
     // local: rank 0 collects, sums in rank order, hands the totals back
     const int world = c0->world;
     if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
@@ -278,7 +283,7 @@ int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count)
 // dst_full[i][p * cnt ...] <- src_loc[p][0 .. cnt) for every rank p, on every handle i; on the handles' main streams
 // or (on_stream2) on their exchange streams.
 int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t cnt,
-                       bool on_stream2)
+                       bool on_stream2, bool peers_idle)
 {
     lzx_ctx *c0 = cs[0];
     if (cnt == 0) return LZX_OK;
@@ -291,6 +296,7 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
         LZX_NCCL(g_rccl.AllGather(src_loc[0], dst_full[0], cnt, ncclDouble, pick_comm(c0, on_stream2), pick(c0, on_stream2)));
         return LZX_OK;
     }
+    if (c0->comm_kind == 3) return lzx_comm_ipc_allgather(c0, src_loc[0], dst_full[0], cnt, on_stream2, peers_idle);
     const int world = c0->world;
     if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
     LZX_TRY(cross_barrier(cs, on_stream2));
@@ -311,11 +317,15 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
 // rank packs once for all peers (one gather kernel), then one grouped send/receive per peer (RCCL: ncclSend / ncclRecv
 // inside one group, xGMI point to point -- no ring, no rank forwards what another one needs) or, inside one process,
 // one device-to-device copy per pair.  On the exchange streams.
-int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc)
+int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc, bool peers_idle)
 {
     lzx_ctx *c0 = cs[0];
     const int world = c0->world;
     if (!c0->sparse) LZX_FAIL(LZX_ERR_STATE, "sparse exchange was not prepared");
+    if (c0->comm_kind == 3) {
+        LZX_TRY(lzx_launch_sx_pack(c0, slice_loc[0], c0->stream2));
+        return lzx_comm_ipc_sparse_chunk1(c0, peers_idle);
+    }
     if (c0->comm_kind == 2) {
         lzx_ctx *c = c0;
         const int me = c->rank;
@@ -366,6 +376,7 @@ int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slic
 // error on every rank at once (LZX_ERR_STATE), never a hang.
 int lzx_comm_check_sparse(lzx_ctx *c)
 {
+    if (c->comm_kind == 3 && c->sparse) return lzx_comm_ipc_check_sparse(c);
     if (c->comm_kind != 2 || !c->sparse) return LZX_OK;
     const u32 world = (u32)c->world;
     std::vector<u32> mine(2 * (size_t)world), all(2 * (size_t)world * world);
@@ -408,7 +419,7 @@ int lzx_comm_check_sparse(lzx_ctx *c)
 // N4 (SURVEY 8 f): the per-iteration all-gather with the slices rounded to fp32 -- half the bytes on the wire.  Every
 // rank converts its slice, the floats are gathered, and every rank widens ALL slices (its own too: all ranks must
 // multiply the same vector) into the fp64 buffer the SpMV reads; sums stay fp64.  Main streams.
-int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc)
+int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc, bool peers_idle)
 {
     lzx_ctx *c0 = cs[0];
     const int world = c0->world;
@@ -419,6 +430,8 @@ int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *sli
     }
     if (c0->comm_kind == 2) {
         LZX_NCCL(g_rccl.AllGather(c0->d_xf32_send, c0->d_xf32_full, cnt, ncclFloat, static_cast<ncclComm_t>(c0->nccl_comm), c0->stream));
+    } else if (c0->comm_kind == 3) {
+        LZX_TRY(lzx_comm_ipc_allgather_f32(c0, c0->d_xf32_send, c0->d_xf32_full, cnt, peers_idle));
     } else {
         if ((int)cs.size() != world) LZX_FAIL(LZX_ERR_STATE, "local communicator needs all %d handles", world);
         LZX_TRY(cross_barrier(cs));

@@ -78,6 +78,7 @@ int lzx_graph_release(lzx_ctx *c)
     c->qf32 = false;
     c->k_done = 0;
     c->ymon_valid = 0;
+    lzx_comm_ipc_unpublish(c);   // peer windows: the peers' mappings of this graph's receive buffers are closed first
     dev_free(c->d_xbuf);
     dev_free(c->d_ybuf);
     dev_free(c->d_io);
@@ -591,9 +592,12 @@ int lzx_graph_prepare(lzx_ctx *c)
         if (!all_ok) { cleanup(); LZX_FAIL(LZX_ERR_STATE, "graph hand-over: a peer rank failed while reshaping its share (see that rank's error)"); }
     }
     if (c->sparse) {
-        rc = lzx_comm_check_sparse(c);   // RCCL: every pair of ranks agrees on what travels, or all of them fail here
+        rc = lzx_comm_check_sparse(c);   // RCCL, peer windows: every pair of ranks agrees on what travels, or all of them fail here
         if (rc != LZX_OK) { cleanup(); return rc; }
     }
+    // peer windows: the hand-over ends with a second collective (the receive buffers allocated below become reachable for the
+    // peers); a rank that fails before it still takes part, through the entry point's lzx_agree_guard
+    c->publish_pending = c->comm_kind == 3 && lzx_exchanges(c);
 
     // ---- 2. this rank's rows ----
     PREP(dev_alloc(&d_old_of_local, c->n_loc_real)); PREP(dev_alloc(&d_deg_local, c->n_loc_real));
@@ -797,6 +801,10 @@ int lzx_graph_prepare(lzx_ctx *c)
     cleanup();
 #undef PREP
 #undef PREP_HIP
+    if (c->publish_pending) {
+        c->publish_pending = false;
+        return lzx_comm_ipc_publish(c, true);
+    }
     return LZX_OK;
 }
 

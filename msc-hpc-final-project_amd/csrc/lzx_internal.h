@@ -72,6 +72,20 @@ static constexpr u32 LZX_PBR_MIN_RUN = 384;   // a (row band, column band) run o
 static constexpr bool LZX_PB_SCATTER_NT = true;   // the scatter pass's code / slot tables as non-temporal loads on large, mostly reduced value streams (test shape pb_scatter_nt)
 static constexpr bool LZX_PB_CARRY_SCAN = true;   // reduced steps: rows that span lanes are summed by a cross-lane scan in registers (fixed order); false: LDS carry slots
 
+// ---- peer-window transport (lzx_ipc.hip) ----
+static constexpr int LZX_IPC_BUFS = 3;   // receive buffers a rank publishes per graph: d_xbuf, d_ybuf, d_xf32_full
+struct lzx_ipc_state {
+    void *win = nullptr;               // this rank's window (flags, mailboxes, board)
+    bool finegrained = false;
+    void *peer_win[64] = {};           // every rank's window as this process sees it ([rank] = win)
+    bool win_opened[64] = {};          // ... mapped with hipIpcOpenMemHandle (to be closed)
+    u64 seq[2] = {0, 0};               // last sequence number used on the main / the exchange stream's channel
+    u64 mail_seq = 0, board_seq = 0;
+    u64 deadline = 0;                  // ticks of the 100 MHz wall clock a wait may take
+    struct Buf { void *mine = nullptr; size_t bytes = 0; void *peer[64] = {}; size_t peer_bytes[64] = {}; bool opened[64] = {}; } buf[LZX_IPC_BUFS];
+    std::vector<u64> sx_dst_off;       // [world] where this rank's packed piece starts inside every peer's chunk 1
+};
+
 struct lzx_ctx {
     int device = 0;
     int cu_count = 256;
@@ -89,7 +103,9 @@ struct lzx_ctx {
 
     // ---- communicator ----
     int world = 1, rank = 0;
-    int comm_kind = 0;                 // 0 none, 1 local (one process, peers[]), 2 RCCL
+    int comm_kind = 0;                 // 0 none, 1 local (one process, peers[]), 2 RCCL, 3 peer windows (one process per rank, lzx_ipc.hip)
+    struct lzx_ipc_state *ipc = nullptr;   // peer windows: this rank's window, the peers' mapped ones, sequence numbers
+    bool publish_pending = false;      // peer windows: the hand-over is past its sync point and has not yet published its receive buffers
     lzx_ctx **peers = nullptr;         // local mode: all handles, index = rank (owned by rank 0's array copy)
     void *nccl_comm = nullptr;
     // in-process groups: the two-double reduction of the lazy loop through a peer-written mailbox -- every handle's reduce
@@ -359,13 +375,16 @@ int lzx_launch_widen_col(lzx_ctx *c, u32 col, double *out);
 
 // ---- lzx_comm.hip ----
 // does the Lanczos loop exchange vectors / reduce scalars through the communicator?
-inline bool lzx_exchanges(const lzx_ctx *c) { return c->world > 1 || (c->force_multi && c->comm_kind == 2); }
+inline bool lzx_exchanges(const lzx_ctx *c) { return c->world > 1 || (c->force_multi && c->comm_kind >= 2); }
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count = 1);   // d_scal[slot .. slot+count) on every handle
+// peers_idle: the caller knows that no rank still reads what the gather overwrites (the loop: an all-reduce lies between
+// every SpMV and the next exchange); otherwise the peer-window transport puts a barrier in front (the others order by
+// construction)
 int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc, double *const *dst_full, size_t count,
-                       bool on_stream2 = false);
+                       bool on_stream2 = false, bool peers_idle = false);
 // chunk 1 of the exchange, sparse form: every handle packs what each peer's rows reference out of slice_loc[i] (its
 // own slice of the new vector) and the packed pieces land in the peers' d_xbuf behind chunk 0; on the exchange streams
-int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
+int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc, bool peers_idle = false);
 int lzx_launch_sx_pack(lzx_ctx *c, const double *slice_loc, hipStream_t st);
 int lzx_comm_check_sparse(lzx_ctx *c);   // RCCL: all ranks' send / receive counts of the sparse chunk agree pairwise, or LZX_ERR_STATE everywhere
 // RCCL: every rank learns whether a rank-LOCAL step (an allocation, a sort, ...) failed on ANY rank -- a 1-value all-reduce
@@ -374,9 +393,10 @@ int lzx_comm_agree(lzx_ctx *c, bool ok, bool *all_ok);
 // A graph hand-over over RCCL contains ONE such sync point (inside lzx_graph_prepare, ahead of the pairwise check of the
 // sparse lists).  A rank whose local steps fail BEFORE it must still cast its vote, or its peers wait there for ever: every
 // hand-over entry point holds a guard, whose destructor votes "failed" if the sync point was never reached.
+int lzx_comm_ipc_publish(lzx_ctx *c, bool ok);   // lzx_ipc.hip, see below
 struct lzx_agree_guard {
     lzx_ctx *c;
-    explicit lzx_agree_guard(lzx_ctx *c_) : c(c_) { if (c) c->agree_pending = c->comm_kind == 2 && lzx_exchanges(c); }
+    explicit lzx_agree_guard(lzx_ctx *c_) : c(c_) { if (c) c->agree_pending = c->comm_kind >= 2 && lzx_exchanges(c); }
     ~lzx_agree_guard()
     {
         if (c && c->agree_pending) {
@@ -384,12 +404,16 @@ struct lzx_agree_guard {
             c->agree_pending = false;
             (void)lzx_comm_agree(c, false, &all);
         }
+        if (c && c->publish_pending) {   // peer windows: failed between the sync point and the publication of its receive buffers
+            c->publish_pending = false;
+            (void)lzx_comm_ipc_publish(c, false);
+        }
     }
     lzx_agree_guard(const lzx_agree_guard &) = delete;
     lzx_agree_guard &operator=(const lzx_agree_guard &) = delete;
 };
 // N4: all-gather of the slices as fp32 into every handle's d_xbuf (converted back to fp64 there), main streams
-int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc);
+int lzx_comm_allgather_fp32(std::vector<lzx_ctx *> &cs, const double *const *slice_loc, bool peers_idle = false);
 int lzx_launch_to_f32(lzx_ctx *c, const double *in, float *out, u64 count);
 int lzx_launch_to_f64(lzx_ctx *c, const float *in, double *out, u64 count);
 // everything queued so far on every handle's `from` stream happens before what is queued next on every `to` stream
@@ -399,3 +423,14 @@ int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream
 bool lzx_comm_mail_usable(std::vector<lzx_ctx *> &cs);
 int lzx_comm_mail_reduce2(std::vector<lzx_ctx *> &cs, u32 parity, bool first);
 void lzx_comm_release(lzx_ctx *c);
+// ---- lzx_ipc.hip: the peer-window transport behind the operations above ----
+void lzx_comm_ipc_release(lzx_ctx *c);
+int lzx_comm_ipc_check(lzx_ctx *c);                          // LZX_ERR_COMM if one of this rank's waits ran into its deadline
+int lzx_comm_ipc_agree(lzx_ctx *c, bool ok, bool *all_ok);
+int lzx_comm_ipc_publish(lzx_ctx *c, bool ok);               // collective, end of a graph hand-over: the receive buffers become reachable for the peers
+void lzx_comm_ipc_unpublish(lzx_ctx *c);                     // before those buffers are freed
+int lzx_comm_ipc_allreduce(lzx_ctx *c, u32 slot, u32 count, int op);
+int lzx_comm_ipc_allgather(lzx_ctx *c, const double *src_loc, double *dst_full, size_t cnt, bool s2, bool peers_idle);
+int lzx_comm_ipc_allgather_f32(lzx_ctx *c, const float *src_loc, float *dst_full, size_t cnt, bool peers_idle);
+int lzx_comm_ipc_sparse_chunk1(lzx_ctx *c, bool peers_idle);
+int lzx_comm_ipc_check_sparse(lzx_ctx *c);

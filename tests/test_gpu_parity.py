@@ -402,6 +402,61 @@ def test_rccl_several_gpus():
     assert out.returncode == 0 and f"RCCL_RANKS_OK {world}" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_windows_across_processes(world):
+    """The several-process path on hardware, on the box's ONE GPU: `world` processes share it (RCCL refuses that --
+    profiles/r4_rccl_one_gpu.txt -- the peer-window transport of csrc/lzx_ipc.hip does not): receive buffers mapped across
+    processes, pushed slices, mailbox all-reduce, every exchange form of the loop against the oracle, the same coefficient
+    bits on every rank (tests/ipc_ranks.py).  On a box with several GPUs LZX_IPC_SPREAD=1 puts one rank on each."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LZX_IPC_TIMEOUT_MS="60000")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29650 + world), os.path.join(here, "ipc_ranks.py")],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and f"IPC_RANKS_OK {world}" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_peer_windows_world1(oracle, pkg):
+    """The same transport at world = 1 with the test hook `exchange_at_world_1`: window creation, the board, publication of
+    the receive buffers, put / wait / mailbox kernels on both streams -- in this very process."""
+    O = oracle
+    rp, ci = O.gen_er(300000, 1500000, 5)
+    n, k = len(rp) - 1, 8
+    x0 = np.ones(n)
+    x = np.random.default_rng(4).random(n)
+    a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, x0, q_colmajor=True)
+    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=1024),
+                 dict(propagation_blocking=1, hub_entries=1024, overlap_exchange=0, lazy_normalisation=0),
+                 dict(propagation_blocking=1, hub_entries=1024, sparse_exchange=0), dict(propagation_blocking=0, exchange_fp32=1)):
+        eng = pkg.Engine(0, exchange_at_world_1=1, **mode)
+        eng.comm_ipc_init(eng.comm_ipc_export(), 0, 1)
+        eng.set_graph_csr(rp, ci)
+        if not mode.get("exchange_fp32"):
+            assert np.allclose(eng.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0), mode
+            a, b, Q, xn, st = eng.lanczos(x0, k)
+            check_leading_coefficients(a, b, a_ref, b_ref, ("ipc1", mode), n=n)
+            check_recurrence(O, rp, ci, a, b, Q, ("ipc1", mode))
+        else:
+            a, b, Q, xn, st = eng.lanczos(x0, k)
+            assert np.allclose(a[:2], a_ref[:2], rtol=1e-6)
+        assert st["iters"] == k
+        eng.close()
+    # a list that is not the handle's own export is refused; so is init without export
+    eng = pkg.Engine(0)
+    with pytest.raises(pkg.LzxError):
+        eng.comm_ipc_init(np.zeros(128, dtype=np.uint8), 0, 1)
+    blob = eng.comm_ipc_export()
+    with pytest.raises(pkg.LzxError):
+        eng.comm_ipc_init(np.zeros(128, dtype=np.uint8), 0, 1)
+    eng.comm_ipc_init(blob, 0, 1)
+    with pytest.raises(pkg.LzxError):
+        eng.comm_ipc_init(blob, 0, 1)     # already wired
+    eng.close()
+
+
 def test_rccl_world1(oracle, pkg):
     """RCCL transport at world = 1: communicator creation, symbol resolution, stream plumbing -- and, with the test hook
     `exchange_at_world_1`, the several-rank loop itself on that communicator: ncclAllReduce of two doubles, ncclAllGather
