@@ -107,7 +107,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("LZX_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # N > 1 only.  rccl: ncclAllGather / grouped send-receive / ncclAllReduce (the default: the collective library is the
+    # safer choice on a node this code has never seen).  ipc: the peer-window transport of csrc/lzx_ipc.hip (buffers mapped
+    # across processes, pushed slices, mailbox all-reduce) -- measured on request until it has run on two physical GPUs.
+    # LZX_BENCH_ONE_GPU=1 puts all ranks on GPU 0 (ipc only; torch's own group over gloo): a functional run of the N > 1
+    # flow on a one-GPU box, not a measurement of scaling.
+    ap.add_argument("--transport", default=os.environ.get("LZX_BENCH_TRANSPORT", "rccl"), choices=["rccl", "ipc"])
     args = ap.parse_args()
+    one_gpu = os.environ.get("LZX_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        args.transport = "ipc"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,8 +144,14 @@ def main():
     if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    tdev = "cpu" if one_gpu else "cuda"   # where the few scalars torch.distributed reduces live
 
     pkg = ge.load_pkg()
     desc, kind, scale, n, draws, seed, k_workload = WORKLOADS[args.workload]
@@ -153,7 +168,7 @@ def main():
         """Every rank learns whether a LOCAL step failed anywhere, before anybody enters the next collective."""
         if dist is None:
             return ok
-        flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+        flag = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return flag.item() == 0.0
 
@@ -172,7 +187,20 @@ def main():
             if e is not None:
                 e.close()
             return None, 0.0
-        if dist is not None:
+        if dist is not None and args.transport == "ipc":
+            blob, ok = np.zeros(pkg.Engine.IPC_BLOB, dtype=np.uint8), True
+            try:
+                blob = e.comm_ipc_export()
+            except Exception as exc:
+                print(f"[bench rank {rank}] window export: {exc}", file=sys.stderr, flush=True)
+                ok = False
+            if not all_ok(ok):
+                e.close()
+                return None, 0.0
+            blobs = [torch.zeros(pkg.Engine.IPC_BLOB, dtype=torch.uint8, device=tdev) for _ in range(world)]
+            dist.all_gather(blobs, torch.from_numpy(blob.copy()).to(tdev))
+            e.comm_ipc_init(torch.cat(blobs).cpu().numpy(), rank, world)   # collective (every rank maps every window)
+        elif dist is not None:
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 uid.copy_(torch.from_numpy(pkg.Engine.unique_id()))
@@ -225,11 +253,11 @@ def main():
         t_rest = time.perf_counter() - t_rest
         m = {}
         if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
             agg = torch.tensor([st["spmv_ms"], float(st["spmv_bytes"]), st["comm_ms"], st["vec_ms"]],
-                               dtype=torch.float64, device="cuda")
+                               dtype=torch.float64, device=tdev)
             mx = agg.clone()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -275,11 +303,14 @@ def main():
                          f"lzx_lanczos_run_steps({K}) on the clock; the other {k_cfg - K} run afterwards, outside it)",
                 "build_id": bid,
                 "partition": "single GPU" if world == 1 else
-                             f"rows dealt round-robin by degree rank over {world} GPUs; per iteration {8 * gi['exchange_recv']} B "
-                             f"received per rank over RCCL (slices of {8 * gi['exchange_slice']} B: only the {gi['active_vertices']} "
+                             f"rows dealt round-robin by degree rank over {world} " + ("ranks sharing ONE GPU" if one_gpu else "GPUs") +
+                             f"; per iteration {8 * gi['exchange_recv']} B received per rank "
+                             + ("pushed by the peers' kernels into mapped buffers (peer-window transport)" if args.transport == "ipc" else "over RCCL") +
+                             f" (slices of {8 * gi['exchange_slice']} B: only the {gi['active_vertices']} "
                              f"vertices that have an edge are exchanged, unnormalised; "
                              + (f"two chunks overlapping the SpMV, the second one sparse: each peer sends only what this rank's rows reference"
-                                if gi.get("exchange_chunk0") else "one all-gather") + ") + 1 two-double all-reduce",
+                                if gi.get("exchange_chunk0") else "one all-gather") + ") + 1 two-double all-reduce" + (" through mailboxes in device memory" if args.transport == "ipc" else ""),
+                "transport": args.transport if world > 1 or launched else None,
                 "exchange_tuning_ms_per_iter": dict(tune) or None,
                 "exchange_chunk0_doubles_per_rank": gi.get("exchange_chunk0", 0),
                 "graph_build_s": round(t_gen, 3),
@@ -295,9 +326,9 @@ def main():
                            "sums cross the two passes) fused with the alpha partial") if gi["pb_entries"] else
                           "k_spmv (+ k_long_finish): CSR SpMV fused with the alpha partial",
                 "achieved": achieved,
-                "peak": HBM_PEAK_GBS * world,
+                "peak": HBM_PEAK_GBS * (1 if one_gpu else world),
                 "unit": "GB/s",
-                "frac": achieved / (HBM_PEAK_GBS * world),
+                "frac": achieved / (HBM_PEAK_GBS * (1 if one_gpu else world)),
                 # PMC bytes per SpMV from the committed rocprofv3 passes (a bench run cannot wrap itself in the profiler);
                 # traffic_build_id is the build_id of the profiled run's own bench line: equal to config.build_id when the
                 # figure was measured on this very build
@@ -343,7 +374,7 @@ def main():
                 dist.barrier()
                 t = time.perf_counter()
                 e.lanczos_run_steps(6)
-                dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
+                dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=tdev)
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
                 best = min(best, float(dt.item()))
             return best / 6 * 1e3

@@ -117,6 +117,8 @@ def _load(path: str, mode: int) -> ctypes.CDLL:
     L.lzx_test_set_shape.argtypes = [_h, ctypes.c_char_p, ctypes.c_int64]
     L.lzx_test_get_shape.restype = ctypes.c_int
     L.lzx_test_get_shape.argtypes = [_h, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]
+    L.lzx_test_allreduce_latency.restype = ctypes.c_int
+    L.lzx_test_allreduce_latency.argtypes = [_h, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
     L.lzx_test_rank_row_sums.restype = ctypes.c_int
     L.lzx_test_rank_row_sums.argtypes = [_h, _f64p, _u32p, _u64p]
     return L
@@ -209,6 +211,12 @@ class Engine:
         _check(self.L.lzx_comm_init_rank(self.h, _p(uid, _u8p), rank, world), "lzx_comm_init_rank", self.L)
 
     IPC_BLOB = 128   # LZX_IPC_BLOB
+
+    def allreduce_latency(self, reps: int = 1000) -> float:
+        """test hook lzx_test_allreduce_latency: microseconds per two-double all-reduce of the wired communicator (collective)."""
+        us = ctypes.c_double()
+        _check(self.L.lzx_test_allreduce_latency(self.h, reps, ctypes.byref(us)), "lzx_test_allreduce_latency", self.L)
+        return us.value
 
     def comm_ipc_export(self) -> np.ndarray:
         """This rank's window for the peer-window transport (include/lzx.h): 128 bytes to be gathered from all ranks."""

@@ -201,6 +201,25 @@ extern "C" int lzx_test_get_shape(lzx_handle c, const char *name, int64_t *value
 }
 
 // test hook (csrc/lzx_test_hooks.h): one rank's local SpMV of x = 1, and where every vertex sits in the full-length layout
+extern "C" int lzx_test_allreduce_latency(lzx_handle c, uint32_t reps, double *us_each)
+{
+    if (!c || !us_each || reps == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_test_allreduce_latency: bad argument");
+    if (c->comm_kind < 2 || !lzx_exchanges(c)) LZX_FAIL(LZX_ERR_STATE, "lzx_test_allreduce_latency: needs a one-process-per-rank communicator");
+    std::vector<lzx_ctx *> cs(1, c);
+    LZX_HIP(hipSetDevice(c->device));
+    LZX_HIP(hipMemsetAsync(c->d_scal, 0, sizeof(double) * 2, c->stream));
+    for (u32 i = 0; i < 5; ++i) LZX_TRY(lzx_comm_allreduce_sum(cs, 0, 2));   // warm-up, and the ranks fall into step
+    LZX_HIP(hipEventRecord(c->ev_a, c->stream));
+    for (u32 i = 0; i < reps; ++i) LZX_TRY(lzx_comm_allreduce_sum(cs, 0, 2));
+    LZX_HIP(hipEventRecord(c->ev_b, c->stream));
+    LZX_HIP(hipStreamSynchronize(c->stream));
+    LZX_TRY(lzx_comm_ipc_check(c));
+    float ms = 0.f;
+    LZX_HIP(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+    *us_each = (double)ms * 1e3 / reps;
+    return LZX_OK;
+}
+
 extern "C" int lzx_test_rank_row_sums(lzx_handle c, double *v_local, uint32_t *layout_pos, uint64_t *n_loc_pad)
 {
     if (!c || !v_local || !layout_pos || !n_loc_pad) LZX_FAIL(LZX_ERR_ARG, "lzx_test_rank_row_sums: bad argument");

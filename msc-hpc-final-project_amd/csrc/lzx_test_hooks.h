@@ -32,3 +32,9 @@ int lzx_test_get_shape(lzx_handle h, const char *name, int64_t *value);
 extern "C"
 #endif
 int lzx_test_rank_row_sums(lzx_handle h, double *v_local, uint32_t *layout_pos, uint64_t *n_loc_pad);
+// Latency of the communicator's two-double all-reduce: `reps` of them queued back to back on the handle's main stream between
+// two events, microseconds each (collective: every rank calls it with the same reps; transports RCCL and peer windows).
+#ifdef __cplusplus
+extern "C"
+#endif
+int lzx_test_allreduce_latency(lzx_handle h, uint32_t reps, double *us_each);

@@ -73,6 +73,15 @@ for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entr
               f"loop {st['loop_ms']:.2f} ms (comm {st['comm_ms']:.2f})", flush=True)
     eng.close()
     dist.barrier()
+# what the mailbox all-reduce costs between processes (here: ranks sharing one GPU; profiles/r4_ipc_one_gpu.txt)
+eng = pkg.Engine(device)
+wire(eng)
+us = eng.allreduce_latency(2000)
+if rank == 0:
+    print(f"[ipc_ranks] world={world}: two-double all-reduce through the mailboxes {us:.2f} us each (2000 back to back)", flush=True)
+assert 0.0 < us < 5000.0
+eng.close()
+dist.barrier()
 # a larger graph on fresh handles: the receive buffers are published again; an R-MAT graph with split rows
 eng = pkg.Engine(device, propagation_blocking=1)
 wire(eng)

@@ -174,6 +174,22 @@ def test_bench_under_torchrun_one_rank():
     assert j["n_gpus"] == 1 and j["steps"] == 10 and j["value"] > 0
 
 
+def test_bench_two_processes_share_the_gpu():
+    """`bench.py --gpus 2` for real across processes on the one-GPU box: LZX_BENCH_ONE_GPU=1 puts both ranks on GPU 0 over
+    the peer-window transport (RCCL refuses two ranks per GPU): engines wired across processes, both exchange modes timed,
+    the overlapped trial under its watchdog, max / sum over ranks, one JSON line from rank 0."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "10", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, LZX_BENCH_ONE_GPU="1", LZX_IPC_TIMEOUT_MS="60000", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    tune = j["config"]["exchange_tuning_ms_per_iter"]
+    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["value"] > 0 and j["config"]["transport"] == "ipc"
+    assert {"single", "overlapped"} <= set(tune) and j["config"]["lanczos_coefficients_finite"]
+
+
 def test_bench_rehearses_the_multi_gpu_flow():
     """The N > 1 flow of bench.py on the one-GPU box: exchange tuning over two engines (single all-gather, two-chunk
     overlapped exchange), the RCCL collectives on the 1-rank communicator (exchange_at_world_1), rank aggregation."""
