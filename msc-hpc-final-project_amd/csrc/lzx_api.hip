@@ -532,6 +532,9 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
         if (mail) {
             // in-process group: each rank's pair goes straight into every peer's mailbox (one barrier, no copies)
             LZX_TRY(lzx_comm_mail_reduce2(cs, j & 1u, first));
+        } else if (multi && lzx_comm_fused_reduce2(c0)) {
+            // peer windows: the rank's two sums are closed and all-reduced by one single-workgroup launch
+            LZX_TRY(lzx_comm_reduce2_allreduce(c0, c0->d_partials, lzx_spmv_partials(c0), c0->d_partials2, first ? 0 : c0->np2_last));
         } else if (multi) {
             for (lzx_ctx *c : cs) {
                 LZX_HIP(hipSetDevice(c->device));

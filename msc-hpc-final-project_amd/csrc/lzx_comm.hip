@@ -245,6 +245,13 @@ int lzx_comm_mail_reduce2(std::vector<lzx_ctx *> &cs, u32 parity, bool first)
 }
 
 
+bool lzx_comm_fused_reduce2(const lzx_ctx *c) { return c->comm_kind == 3; }
+
+int lzx_comm_reduce2_allreduce(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb)
+{
+    return lzx_comm_ipc_allreduce(c, 0, 2, 0, pa, na, pb, nb);
+}
+
 __global__ void k_sum_ranks_n(const double *vals, int world, u32 count, double *out)
 {
     for (u32 i = 0; i < count; ++i) {

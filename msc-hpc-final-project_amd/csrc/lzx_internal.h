@@ -422,6 +422,9 @@ int lzx_comm_order(std::vector<lzx_ctx *> &cs, bool from_stream2, bool to_stream
 // returns false (nothing queued) when the group cannot use mailboxes (no peer access): the caller takes the all-reduce
 bool lzx_comm_mail_usable(std::vector<lzx_ctx *> &cs);
 int lzx_comm_mail_reduce2(std::vector<lzx_ctx *> &cs, u32 parity, bool first);
+// peer windows, lazy loop: [sum pa, sum pb] of this rank closed from the block partials AND all-reduced into d_scal[0..1] by one launch
+bool lzx_comm_fused_reduce2(const lzx_ctx *c);
+int lzx_comm_reduce2_allreduce(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb);
 void lzx_comm_release(lzx_ctx *c);
 // ---- lzx_ipc.hip: the peer-window transport behind the operations above ----
 void lzx_comm_ipc_release(lzx_ctx *c);
@@ -429,7 +432,7 @@ int lzx_comm_ipc_check(lzx_ctx *c);                          // LZX_ERR_COMM if 
 int lzx_comm_ipc_agree(lzx_ctx *c, bool ok, bool *all_ok);
 int lzx_comm_ipc_publish(lzx_ctx *c, bool ok);               // collective, end of a graph hand-over: the receive buffers become reachable for the peers
 void lzx_comm_ipc_unpublish(lzx_ctx *c);                     // before those buffers are freed
-int lzx_comm_ipc_allreduce(lzx_ctx *c, u32 slot, u32 count, int op);
+int lzx_comm_ipc_allreduce(lzx_ctx *c, u32 slot, u32 count, int op, const double *pa = nullptr, u32 na = 0, const double *pb = nullptr, u32 nb = 0);
 int lzx_comm_ipc_allgather(lzx_ctx *c, const double *src_loc, double *dst_full, size_t cnt, bool s2, bool peers_idle);
 int lzx_comm_ipc_allgather_f32(lzx_ctx *c, const float *src_loc, float *dst_full, size_t cnt, bool peers_idle);
 int lzx_comm_ipc_sparse_chunk1(lzx_ctx *c, bool peers_idle);

@@ -24,6 +24,8 @@
 #include <cstring>
 
 #include "lzx_internal.h"
+#include "lzx_spmv_body.h"
+#include "lzx_reduce.h"
 
 namespace {
 
@@ -95,8 +97,10 @@ __global__ void __launch_bounds__(64) k_ipc_wait(const unsigned long long *flags
     if (threadIdx.x < world && !spin_until(flags + threadIdx.x, seq, deadline_ticks)) atomicCAS(err, 0u, 1u + threadIdx.x);
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) k_ipc_put(PutArgs<T> a, u32 world, u32 first_peer, FlagPeers sig, u64 seq, unsigned int *done)
+// WT: the data as write-through stores (system-scope relaxed atomic stores: nothing stays dirty in this XCD's L2, so the
+// workgroup's release fence below has nothing to write back)
+template <typename T, bool WT>
+__global__ void __launch_bounds__(1024) k_ipc_put(PutArgs<T> a, u32 world, u32 first_peer, FlagPeers sig, u64 seq, unsigned int *done)
 {
     // peers in a rotation that starts behind this rank: at any moment the ranks of a node write to different peers
     for (u32 t = 0; t < world; ++t) {
@@ -104,31 +108,47 @@ __global__ void __launch_bounds__(256) k_ipc_put(PutArgs<T> a, u32 world, u32 fi
         const T *__restrict__ s = a.src[p];
         T *__restrict__ d = a.dst[p];
         const u32 n = a.cnt[p];
-        for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) d[i] = s[i];
+        for (u32 i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
+            if (WT) __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else d[i] = s[i];
+        }
     }
-    __threadfence_system();
+    // One release per workgroup, not per wavefront (a system-scope release walks this XCD's whole L2: 16 of them per workgroup
+    // made the kernel four times slower): the barrier orders every wavefront's stores before wavefront 0's fence, whose
+    // release is cumulative over them; the counter chains the workgroups to the last one, which signals the peers.
     __syncthreads();
     __shared__ bool last;
     if (threadIdx.x == 0) {
-        last = atomicAdd(done, 1u) == gridDim.x - 1;
-        if (last) atomicExch(done, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (last) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (last) {
-        __threadfence_system();
-        if (threadIdx.x < world) __hip_atomic_store(sig.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (last && threadIdx.x < world) __hip_atomic_store(sig.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// op 0: sum in rank order; 1: minimum
-__global__ void __launch_bounds__(64) k_ipc_allreduce(MailPeersIpc out, const MailSlot *in, double *scal, u32 count, u32 world, u64 seq,
-                                                      u64 deadline_ticks, unsigned int *err, int op)
+// op 0: sum in rank order; 1: minimum.  pa != nullptr: the rank's two values are first closed from block partials
+// (sum pa[0..na), sum pb[0..nb)) -- k_reduce2 and the all-reduce in one launch.
+__global__ void __launch_bounds__(LZX_VEC_BLOCK) k_ipc_allreduce(MailPeersIpc out, const MailSlot *in, double *scal, u32 count, u32 world, u64 seq,
+                                                                 u64 deadline_ticks, unsigned int *err, int op, const double *pa, u32 na,
+                                                                 const double *pb, u32 nb)
 {
     __shared__ double vals[64][8];
+    __shared__ double sh[4];
+    __shared__ double own[8];
     const u32 p = threadIdx.x;
+    if (pa) {
+        const double a = block_sum_fixed_256(pa, na, sh);
+        __syncthreads();
+        const double b = block_sum_fixed_256(pb, nb, sh);   // nb == 0 (first iteration): 0, as k_reduce2 leaves it
+        if (p == 0) { own[0] = a; own[1] = b; }
+    } else if (p < count) {
+        own[p] = scal[p];
+    }
+    __syncthreads();
     if (p < world) {
         MailSlot *o = out.slot[p];
-        for (u32 i = 0; i < count; ++i) o->v[i] = scal[i];
+        for (u32 i = 0; i < count; ++i) o->v[i] = own[i];
         __hip_atomic_store(&o->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!spin_until(&in[p].seq, seq, deadline_ticks)) atomicCAS(err, 0u, 1u + p);
         for (u32 i = 0; i < count; ++i) vals[p][i] = __hip_atomic_load(&in[p].v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -182,10 +202,14 @@ template <typename T> int queue_put(lzx_ctx *c, bool s2, const PutArgs<T> &a)
 {
     u64 total = 0;
     for (int p = 0; p < c->world; ++p) total += a.cnt[p];
-    const u32 grid = (u32)std::min<u64>((u64)c->cu_count * 2, std::max<u64>(1, (total + 2047) / 2048));
+    static const int grid_env = getenv("LZX_IPC_PUT_GRID") ? atoi(getenv("LZX_IPC_PUT_GRID")) : 0;
+    static const int wt_env = getenv("LZX_IPC_PUT_WT") ? atoi(getenv("LZX_IPC_PUT_WT")) : 1;
+    const u32 cap = grid_env > 0 ? (u32)grid_env : (u32)c->cu_count;   // 8 MB local copy: 64 workgroups 10.7 us, 256 8.9 us (one release each)
+    const u32 grid = (u32)std::min<u64>(cap, std::max<u64>(1, (total + 8191) / 8192));
     const u64 seq = ++c->ipc->seq[s2 ? 1 : 0];
     Window *w = static_cast<Window *>(c->ipc->win);
-    hipLaunchKernelGGL(k_ipc_put<T>, dim3(grid), dim3(256), 0, pick(c, s2), a, (u32)c->world, (u32)((c->rank + 1) % c->world), flag_peers(c, s2), seq,
+    auto kern = wt_env ? k_ipc_put<T, true> : k_ipc_put<T, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, pick(c, s2), a, (u32)c->world, (u32)((c->rank + 1) % c->world), flag_peers(c, s2), seq,
                        &w->done[s2 ? 1 : 0]);
     LZX_HIP(hipGetLastError());
     return queue_wait(c, s2, seq);
@@ -473,17 +497,18 @@ void lzx_comm_ipc_unpublish(lzx_ctx *c)
     if (c->comm_kind == 3 && c->ipc) close_peer_bufs(c);
 }
 
-int lzx_comm_ipc_allreduce(lzx_ctx *c, u32 slot, u32 count, int op)
+int lzx_comm_ipc_allreduce(lzx_ctx *c, u32 slot, u32 count, int op, const double *pa, u32 na, const double *pb, u32 nb)
 {
-    if (count > 8) LZX_FAIL(LZX_ERR_LIMIT, "peer windows: all-reduce of %u values", count);
+    if (count > 8 || (pa && count != 2)) LZX_FAIL(LZX_ERR_LIMIT, "peer windows: all-reduce of %u values", count);
     lzx_ipc_state *s = c->ipc;
     Window *w = static_cast<Window *>(s->win);
     const u64 seq = ++s->mail_seq;
     const u32 parity = (u32)(seq & 1u);
     MailPeersIpc out{};
     for (int p = 0; p < c->world; ++p) out.slot[p] = &static_cast<Window *>(s->peer_win[p])->mail[parity][c->rank];
-    hipLaunchKernelGGL(k_ipc_allreduce, dim3(1), dim3(64), 0, c->stream, out, w->mail[parity], c->d_scal + slot, count, (u32)c->world, seq, s->deadline,
-                       &w->err, op);
+    // (only wavefront 0 of the workgroup ever spins; the other three are done after the block sums)
+    hipLaunchKernelGGL(k_ipc_allreduce, dim3(1), dim3(LZX_VEC_BLOCK), 0, c->stream, out, w->mail[parity], c->d_scal + slot, count, (u32)c->world, seq,
+                       s->deadline, &w->err, op, pa, na, pb, nb);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }
