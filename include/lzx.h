@@ -264,7 +264,13 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           1 M- and 10 M-vertex benchmark graphs at k = 50), also together with "reorthogonalise".  A parity
  *                           instrument, not a fast path (about 70 ms per iteration at 10 M vertices); one rank only.
  *                           Default 0.  May be changed between decompositions.
- * These ten are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
+ *   "placement_trials"      t >= 0: at the end of a graph hand-over in blocked mode the value stream between the SpMV's two
+ *                           passes is allocated t more times, the SpMV timed with each candidate and the fastest kept (a few
+ *                           SpMVs of set-up time each; results are bit-identical whichever wins).  Where the driver places
+ *                           that one buffer decides up to 15 % of the SpMV on uniform graphs and 1-2 % on R-MAT ones for the
+ *                           life of the allocation -- the reference's cudaMalloc blocks (cu_lanczos.cu:37-86) have no
+ *                           counterpart.  Default 4; 0 = take the first allocation.
+ * These eleven are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
  * "phase_mask", "exchange_at_world_1", ...) exist only in liblzx_dbg.so, the same sources built with -DLZX_DEBUG_KNOBS
  * (`make debug`); tools/perf_probe.py and the tests that need them load that library.                               */
 int lzx_set_option(lzx_handle h, const char *name, int64_t value);

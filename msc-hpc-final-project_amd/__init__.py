@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "liblzx.so")
 DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
 # what the product library's lzx_set_option knows (include/lzx.h); any other option name selects the debug library
 PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "exchange_fp32",
-                   "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32", "reference_order")
+                   "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32", "reference_order", "placement_trials")
 
 # test-only shapes the product library accepts through lzx_test_set_shape (csrc/lzx_test_hooks.h): they select among code
 # paths the product contains (what large graphs get by themselves), so tests that force them still run liblzx.so

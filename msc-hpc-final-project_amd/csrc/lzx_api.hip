@@ -113,6 +113,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "reorthogonalise")) c->reorth_opt = value;
     else if (!strcmp(name, "basis_fp32")) c->qf32_opt = value;
     else if (!strcmp(name, "reference_order")) c->ref_order_opt = value;
+    else if (!strcmp(name, "placement_trials")) c->place_opt = value;
 #ifdef LZX_DEBUG_KNOBS
     // experiment knobs and test hooks: only in liblzx_dbg.so (make debug), which tests/ and tools/perf_probe.py load
     // when they ask for one of these; the product library does not know the names
@@ -196,6 +197,9 @@ extern "C" int lzx_test_get_shape(lzx_handle c, const char *name, int64_t *value
     if (!strcmp(name, "gather_items_dealt")) *value = c->pb ? c->pb_n_static : 0;
     else if (!strcmp(name, "gather_items_drawn")) *value = c->pb ? c->pb_n_dyn : 0;
     else if (!strcmp(name, "gather_workgroups")) *value = c->pb ? c->pb_gather_grid : 0;
+    else if (!strcmp(name, "placement_tried")) *value = c->place_tried;
+    else if (!strcmp(name, "placement_kept")) *value = c->place_kept;
+    else if (!strncmp(name, "placement_us_", 13) && name[13] >= '0' && name[13] <= '7' && !name[14]) *value = (int64_t)(c->place_ms[name[13] - '0'] * 1e3f);
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_get_shape: unknown shape '%s'", name);
     return LZX_OK;
 }
@@ -1264,6 +1268,71 @@ extern "C" int lzx_bench_spmv(lzx_handle c, uint32_t reps, double *avg_ms, doubl
             }
             LZX_HIP(hipStreamSynchronize(c->stream));
             (void)hipFree(buf);
+        }
+    }
+    if (getenv("LZX_RELOC_SHOP")) {
+        // Which array's PLACEMENT carries the SpMV's "state" (profiles/NOTES.md: engines built one after the other in one
+        // process differ by 1.5-5 % on C3, 4-20 % on ER, each keeping its time for life)?  Every large array in turn is copied
+        // into several fresh allocations -- all kept alive, so they are physically distinct -- and the SpMV timed with the
+        // array in each of them, everything else in place.
+        auto time_spmv = [&](double *avg, double *mn) -> int {
+            double tot = 0.0, best = 1e300;
+            for (int r = 0; r < 8; ++r) {
+                LZX_HIP(hipEventRecord(c->ev_a, c->stream));
+                LZX_TRY(lzx_launch_spmv(c, l));
+                LZX_HIP(hipEventRecord(c->ev_b, c->stream));
+                LZX_HIP(hipEventSynchronize(c->ev_b));
+                float ms = 0.f;
+                LZX_HIP(hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+                tot += ms;
+                if (ms < best) best = ms;
+            }
+            *avg = tot / 8;
+            *mn = best;
+            return LZX_OK;
+        };
+        struct Named { const char *name; void **slot; };
+        Named arrays[] = {{"pb_val", (void **)&c->d_pb_val}, {"pb_lrow", (void **)&c->d_pb_lrow}, {"pbr_code", (void **)&c->d_pbr_code},
+                          {"pb_lcol", (void **)&c->d_pb_lcol}, {"pb_dst", (void **)&c->d_pb_dst}, {"sell_cols", (void **)&c->d_sell_cols},
+                          {"long_cols", (void **)&c->d_long_cols}, {"pbr_base", (void **)&c->d_pbr_base}, {"v", (void **)&c->d_v}};
+        double a0 = 0, m0 = 0;
+        LZX_TRY(time_spmv(&a0, &m0));
+        fprintf(stderr, "[lzx shop] as built: spmv avg %.4f min %.4f ms\n", a0, m0);
+        for (const Named &nm : arrays) {
+            if (!*nm.slot) continue;
+            size_t bytes = 0;
+            if (hipMemPtrGetInfo(*nm.slot, &bytes) != hipSuccess || bytes < (8u << 20)) { (void)hipGetLastError(); continue; }
+            void *orig = *nm.slot;
+            void *fresh[5] = {};
+            fprintf(stderr, "[lzx shop] %s (%zu MB at %p):", nm.name, bytes >> 20, orig);
+            for (int t = 0; t < 5; ++t) {
+                if (hipMalloc(&fresh[t], bytes) != hipSuccess) { (void)hipGetLastError(); fresh[t] = nullptr; break; }
+                LZX_HIP(hipMemcpyAsync(fresh[t], orig, bytes, hipMemcpyDeviceToDevice, c->stream));
+                *nm.slot = fresh[t];
+                if (nm.slot == (void **)&c->d_v) l.v = c->d_v;
+                double a = 0, m = 0;
+                int rc = time_spmv(&a, &m);
+                *nm.slot = orig;
+                if (nm.slot == (void **)&c->d_v) l.v = c->d_v;
+                LZX_TRY(rc);
+                fprintf(stderr, " %.4f", m);
+                if (nm.slot == (void **)&c->d_pb_val && c->pb) {   // which pass feels the placement: the gather pass alone, the scatter pass alone
+                    const int64_t keep = c->phase_mask_opt;
+                    double ag = 0, mg = 0, as = 0, msc = 0;
+                    *nm.slot = fresh[t];
+                    c->phase_mask_opt = keep | 4;
+                    rc = time_spmv(&ag, &mg);
+                    c->phase_mask_opt = keep | 8;
+                    if (rc == LZX_OK) rc = time_spmv(&as, &msc);
+                    c->phase_mask_opt = keep;
+                    *nm.slot = orig;
+                    LZX_TRY(rc);
+                    fprintf(stderr, " (gather alone %.4f, scatter alone %.4f)", mg, msc);
+                }
+            }
+            fprintf(stderr, " ms (min of 8 each)\n");
+            LZX_HIP(hipStreamSynchronize(c->stream));
+            for (void *f : fresh) if (f) (void)hipFree(f);
         }
     }
     if (getenv("LZX_TRACE_SPMV")) {

@@ -801,11 +801,13 @@ int lzx_graph_prepare(lzx_ctx *c)
     cleanup();
 #undef PREP
 #undef PREP_HIP
+    rc = lzx_pb_place_values(c);   // option placement_trials: the value stream where the SpMV runs fastest (rank-local, no collective)
     if (c->publish_pending) {
         c->publish_pending = false;
-        return lzx_comm_ipc_publish(c, true);
+        const int rp = lzx_comm_ipc_publish(c, rc == LZX_OK);
+        return rc != LZX_OK ? rc : rp;
     }
-    return LZX_OK;
+    return rc;
 }
 
 // --------------------------------------------------------------------------------------------------

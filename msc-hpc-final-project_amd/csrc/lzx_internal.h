@@ -280,6 +280,13 @@ struct lzx_ctx {
     // norm one left-to-right accumulator in the caller's vertex order -- the reduction orders serial/ fixes (SPMV.cc:24-27,
     // lanczos.cc:155-171), so alpha / beta / Q meet the oracle's bit for bit at any k.  A parity instrument, not a fast path.
     int64_t ref_order_opt = -1;
+    // Option placement_trials (blocked mode): at the end of a graph hand-over the value stream between the two passes is
+    // allocated this many more times, the SpMV timed with each, the fastest kept -- where the driver puts that buffer
+    // decides 15 % of the Erdos-Renyi SpMV and 1-2 % of the R-MAT one (lzx_pb.hip: lzx_pb_place_values).  -1: default (4), 0: off.
+    int64_t place_opt = -1;
+    u32 place_tried = 0;               // allocations timed at the last hand-over (incl. the first one), and their SpMV times
+    float place_ms[8] = {};
+    u32 place_kept = 0;
     // N4 remainder: the resident basis is STORED as fp32 (d_Qf), the recurrence keeps its three live vectors in fp64
     // (d_ring); lzx_multout and the host fetch read the fp32 columns.  Lazy loop only.  Off by default.
     int64_t qf32_opt = -1;
@@ -317,6 +324,7 @@ int lzx_graph_prepare(lzx_ctx *c);   // builds this rank's share from d_row_ptr/
 int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, const u32 *d_deg_local,
                    const u32 *d_nh_off, const std::vector<u32> &h_nh, u64 total);
 void lzx_pb_release(lzx_ctx *c);
+int lzx_pb_place_values(lzx_ctx *c);   // end of a hand-over: option placement_trials
 // chunk1_ready (may be null): event after which the second chunk of the exchange layout is valid in x
 // phases: 1 = scatter pass, 2 = gather (+ finish) pass, 3 = both
 struct SpmvArgs;   // lzx_spmv_body.h

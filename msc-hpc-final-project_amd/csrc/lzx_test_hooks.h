@@ -18,7 +18,8 @@ extern "C"
 #endif
 int lzx_test_set_shape(lzx_handle h, const char *name, int64_t value);
 // what shape the tables of the handle's graph took: "gather_items_dealt" / "gather_items_drawn" (static lists / dynamic tail of
-// the gather pass), "gather_workgroups"
+// the gather pass), "gather_workgroups", "placement_tried" / "placement_kept" / "placement_us_<i>" (option placement_trials: candidates of
+// the value stream timed at the last hand-over, the one kept, the SpMV time of candidate i in microseconds"
 #ifdef __cplusplus
 extern "C"
 #endif

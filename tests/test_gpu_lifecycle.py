@@ -152,3 +152,31 @@ def test_larger_graph_on_a_handle_that_ran_the_optional_loop_forms(pkg, oracle):
     a, b, _, _, _ = eng.lanczos(np.ones(eng.n), 12, want_q=False)
     assert np.array_equal(a, a64) and np.array_equal(b, b64)
     eng.close()
+
+
+def test_placement_trials_change_no_bit(pkg):
+    """Option placement_trials: the value stream of the blocked SpMV is allocated a few more times at the hand-over and the
+    fastest placement kept (lzx_pb.hip: lzx_pb_place_values).  The winner is a matter of speed only: same SpMV bits, same
+    coefficients as with the first allocation; a stream the caches hold is left alone."""
+    n, draws = 2_000_000, 20_000_000
+    x = np.random.default_rng(11).random(n)
+    out = {}
+    for trials in (0, 3):
+        eng = pkg.Engine(0, propagation_blocking=1, placement_trials=trials)
+        eng.gen_er(n, draws, 21)
+        assert eng.info()["pb_values"] * 8 > (128 << 20)
+        tried = eng.shape("placement_tried")
+        assert tried == (0 if trials == 0 else trials + 1), tried
+        if trials:
+            times = [eng.shape(f"placement_us_{i}") for i in range(tried)]
+            kept = eng.shape("placement_kept")
+            assert all(t > 0 for t in times) and times[kept] == min(times), (times, kept)
+        y = eng.spmv(x)
+        a, b, _, xn, _ = eng.lanczos(np.ones(n), 6)
+        out[trials] = (y, a, b)
+        eng.close()
+    assert np.array_equal(out[0][0], out[3][0]) and np.array_equal(out[0][1], out[3][1]) and np.array_equal(out[0][2], out[3][2])
+    small = pkg.Engine(0, propagation_blocking=1, hub_entries=256)
+    small.gen_er(200_000, 1_000_000, 3)
+    assert small.shape("placement_tried") == 0
+    small.close()
