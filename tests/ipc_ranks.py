@@ -93,6 +93,23 @@ eng.set_graph_csr(rp, ci)      # and a second graph on the SAME wired handle
 assert np.allclose(eng.spmv(x), y_ref, rtol=1e-13, atol=0)
 eng.close()
 dist.barrier()
+# a peer that never arrives is an error after the deadline, not a hang: rank 0 enters a collective alone
+import time
+os.environ["LZX_IPC_TIMEOUT_MS"] = "400"
+eng = pkg.Engine(device)
+wire(eng)
+if rank == 0:
+    t = time.time()
+    try:
+        eng.allreduce_latency(4)
+        raise AssertionError("an all-reduce without the peers returned")
+    except pkg.LzxError as exc:
+        waited = time.time() - t
+        assert "did not arrive" in str(exc) and waited < 10.0, (str(exc), waited)
+        print(f"[ipc_ranks] world={world}: a collective entered by rank 0 alone failed after {waited:.2f} s: {str(exc)[-110:]}", flush=True)
+dist.barrier()
+eng.close()
+dist.barrier()
 if rank == 0:
     print(f"IPC_RANKS_OK {world}", flush=True)
 dist.destroy_process_group()
