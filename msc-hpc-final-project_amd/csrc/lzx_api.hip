@@ -204,7 +204,7 @@ extern "C" int lzx_test_get_shape(lzx_handle c, const char *name, int64_t *value
     return LZX_OK;
 }
 
-// test hook (csrc/lzx_test_hooks.h): one rank's local SpMV of x = 1, and where every vertex sits in the full-length layout
+// test hook (csrc/lzx_test_hooks.h): what one two-double all-reduce of the wired communicator costs, back to back
 extern "C" int lzx_test_allreduce_latency(lzx_handle c, uint32_t reps, double *us_each)
 {
     if (!c || !us_each || reps == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_test_allreduce_latency: bad argument");
@@ -224,6 +224,7 @@ extern "C" int lzx_test_allreduce_latency(lzx_handle c, uint32_t reps, double *u
     return LZX_OK;
 }
 
+// test hook (csrc/lzx_test_hooks.h): one rank's local SpMV of x = 1, and where every vertex sits in the full-length layout
 extern "C" int lzx_test_rank_row_sums(lzx_handle c, double *v_local, uint32_t *layout_pos, uint64_t *n_loc_pad)
 {
     if (!c || !v_local || !layout_pos || !n_loc_pad) LZX_FAIL(LZX_ERR_ARG, "lzx_test_rank_row_sums: bad argument");
