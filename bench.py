@@ -174,8 +174,8 @@ def main():
 
     def make_engine(**options):
         """(engine, seconds of graph build), or (None, 0) on EVERY rank when a local step failed on any of them.
-        Local steps (handle creation, graph generation + reshaping) are guarded and agreed on with an all-reduce;
-        the collective ones (id broadcast, ncclCommInitRank) run outside any try: an error there is fatal anyway."""
+        Local steps (handle creation, graph generation + reshaping) and the communicator's creation are guarded and
+        agreed on with an all-reduce."""
         if rehearse:
             options = dict(options, exchange_at_world_1=1)
         e = None
@@ -199,13 +199,28 @@ def main():
                 return None, 0.0
             blobs = [torch.zeros(pkg.Engine.IPC_BLOB, dtype=torch.uint8, device=tdev) for _ in range(world)]
             dist.all_gather(blobs, torch.from_numpy(blob.copy()).to(tdev))
-            e.comm_ipc_init(torch.cat(blobs).cpu().numpy(), rank, world)   # collective (every rank maps every window)
+            try:
+                e.comm_ipc_init(torch.cat(blobs).cpu().numpy(), rank, world)   # collective (every rank maps every window)
+            except Exception as exc:
+                print(f"[bench rank {rank}] peer windows: {exc}", file=sys.stderr, flush=True)
+                ok = False
+            if not all_ok(ok):
+                e.close()
+                return None, 0.0
         elif dist is not None:
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 uid.copy_(torch.from_numpy(pkg.Engine.unique_id()))
             dist.broadcast(uid, 0)
-            e.comm_init_rank(uid.cpu().numpy(), rank, world)
+            ok = True
+            try:
+                e.comm_init_rank(uid.cpu().numpy(), rank, world)
+            except Exception as exc:   # (a rank that fails here alone leaves its peers inside ncclCommInitRank: nothing to be done about that)
+                print(f"[bench rank {rank}] RCCL communicator: {exc}", file=sys.stderr, flush=True)
+                ok = False
+            if not all_ok(ok):
+                e.close()
+                return None, 0.0
         t = time.perf_counter()
         ok = True
         try:
@@ -268,7 +283,8 @@ def main():
         alpha, beta, _ = e.lanczos_fetch(k_cfg)
         t_out = time.perf_counter() - t_out
         m.update(elapsed=elapsed, t_in=t_in, t_out=t_out, t_rest=t_rest,
-                 finite=bool(np.isfinite(alpha).all() and np.isfinite(beta).all()))
+                 finite=bool(np.isfinite(alpha).all() and np.isfinite(beta).all()),
+                 head=np.concatenate([alpha[:3], beta[:2]]))   # alpha_0..2, beta_0..1: compared across exchange modes / with the closed form
         return m
 
     stream = None
@@ -318,6 +334,8 @@ def main():
                 # download of alpha / beta included -- what a caller holding host buffers sees (rank 0's clock)
                 "iters_per_sec_including_host_transfers": k_cfg / (elapsed + m["t_rest"] + m["t_in"] + m["t_out"]),
                 "lanczos_coefficients_finite": m["finite"],
+                # x0 = ones: alpha_0 = q_0' A q_0 = nnz / n exactly (a check of the run itself, not of parity -- that is tests/)
+                "alpha0_vs_closed_form_rel": abs(float(m["head"][0]) * gi["n"] / gi["nnz"] - 1.0) if gi["nnz"] else None,
             },
             "roofline": {
                 "bound": "hbm",
@@ -380,6 +398,12 @@ def main():
             return best / 6 * 1e3
 
         eng, t_gen = make_engine(overlap_exchange=0)
+        if eng is None and args.transport == "rccl" and not rehearse:
+            # the collective library would not start on this node: the transport that needs none (csrc/lzx_ipc.hip)
+            print(f"[bench rank {rank}] no engine over RCCL: trying the peer-window transport", file=sys.stderr, flush=True)
+            args.transport = "ipc"
+            tune["transport_fallback"] = "rccl -> ipc"
+            eng, t_gen = make_engine(overlap_exchange=0)
         if eng is None:
             sys.exit(f"bench.py rank {rank}: could not build the engine (see stderr of the failing rank)")
         m_single = measure(eng)
@@ -417,13 +441,23 @@ def main():
                 tune["overlapped_received_MB_per_rank"] = 8e-6 * alt.info()["exchange_recv"]
                 if rank == 0:
                     out["config"]["exchange_tuning_ms_per_iter"] = dict(tune)
-                if tune["overlapped"] < tune["single"]:
+                if tune["overlapped"] < tune["single"] or os.environ.get("LZX_BENCH_FORCE_ALT") == "1":   # (the variable: tests run the comparison below)
                     m_alt, ok = None, True
                     try:
                         m_alt = measure(alt)
                     except Exception as exc:
                         print(f"[bench rank {rank}] overlapped exchange failed in the timed run: {exc}", file=sys.stderr, flush=True)
                         ok = False
+                    # the two exchange forms must describe the same decomposition: alpha_0..2, beta_0..1 to rounding
+                    if ok and m_alt is not None:
+                        dev = float(np.max(np.abs(m_alt["head"] - m_single["head"]) / np.maximum(np.abs(m_single["head"]), 1e-300)))
+                        tune["overlapped_vs_single_coefficients_rel"] = dev
+                        if not dev < 1e-9:
+                            print(f"[bench rank {rank}] overlapped exchange REJECTED: leading coefficients differ from the single all-gather's by {dev:.2e}",
+                                  file=sys.stderr, flush=True)
+                            ok = False
+                        if rank == 0:
+                            out["config"]["exchange_tuning_ms_per_iter"] = dict(tune)
                     if all_ok(ok) and m_alt["elapsed"] < m_single["elapsed"]:
                         if rank == 0:
                             out = line(alt, m_alt, tune)

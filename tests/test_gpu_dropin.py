@@ -180,7 +180,7 @@ def test_bench_two_processes_share_the_gpu():
     the overlapped trial under its watchdog, max / sum over ranks, one JSON line from rank 0."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "10", "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, LZX_BENCH_ONE_GPU="1", LZX_IPC_TIMEOUT_MS="60000", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                         env=dict(os.environ, LZX_BENCH_ONE_GPU="1", LZX_IPC_TIMEOUT_MS="60000", HSA_ENABLE_IPC_MODE_LEGACY="0", LZX_BENCH_FORCE_ALT="1"))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
@@ -188,6 +188,9 @@ def test_bench_two_processes_share_the_gpu():
     tune = j["config"]["exchange_tuning_ms_per_iter"]
     assert j["n_gpus"] == 2 and j["steps"] == 10 and j["value"] > 0 and j["config"]["transport"] == "ipc"
     assert {"single", "overlapped"} <= set(tune) and j["config"]["lanczos_coefficients_finite"]
+    # the overlapped exchange (two chunks, the second sparse, on the exchange stream) was measured in full and describes the
+    # same decomposition as the single all-gather: leading coefficients equal to rounding; alpha_0 = nnz / n exactly
+    assert tune["overlapped_vs_single_coefficients_rel"] < 1e-9 and j["config"]["alpha0_vs_closed_form_rel"] < 1e-14
 
 
 def test_bench_rehearses_the_multi_gpu_flow():
