@@ -269,7 +269,7 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           SpMVs of set-up time each; results are bit-identical whichever wins).  Where the driver places
  *                           that one buffer decides up to 15 % of the SpMV on uniform graphs and 1-2 % on R-MAT ones for the
  *                           life of the allocation -- the reference's cudaMalloc blocks (cu_lanczos.cu:37-86) have no
- *                           counterpart.  Default 4; 0 = take the first allocation.
+ *                           counterpart.  Default 7 (fewer when the stream is several GB); 0 = take the first allocation.
  * These eleven are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
  * "phase_mask", "exchange_at_world_1", ...) exist only in liblzx_dbg.so, the same sources built with -DLZX_DEBUG_KNOBS
  * (`make debug`); tools/perf_probe.py and the tests that need them load that library.                               */

@@ -282,7 +282,7 @@ struct lzx_ctx {
     int64_t ref_order_opt = -1;
     // Option placement_trials (blocked mode): at the end of a graph hand-over the value stream between the two passes is
     // allocated this many more times, the SpMV timed with each, the fastest kept -- where the driver puts that buffer
-    // decides 15 % of the Erdos-Renyi SpMV and 1-2 % of the R-MAT one (lzx_pb.hip: lzx_pb_place_values).  -1: default (4), 0: off.
+    // decides 15 % of the Erdos-Renyi SpMV and 1-2 % of the R-MAT one (lzx_pb.hip: lzx_pb_place_values).  -1: default (7, fewer for streams of several GB), 0: off.
     int64_t place_opt = -1;
     u32 place_tried = 0;               // allocations timed at the last hand-over (incl. the first one), and their SpMV times
     float place_ms[8] = {};

@@ -1052,8 +1052,11 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
 int lzx_pb_place_values(lzx_ctx *c)
 {
     c->place_tried = c->place_kept = 0;
-    const u32 trials = c->place_opt >= 0 ? (u32)std::min<int64_t>(c->place_opt, 7) : 4u;
     const size_t bytes = sizeof(double) * (c->pb_values + 8);
+    // default: seven more candidates, fewer where they would hold more than 16 GB among them (the driver clears what it hands out:
+    // a 10 GB allocation takes most of a second)
+    const u32 trials = c->place_opt >= 0 ? (u32)std::min<int64_t>(c->place_opt, 7)
+                                         : (u32)std::min<u64>(7, std::max<u64>(1, (16ull << 30) / std::max<size_t>(bytes, 1)));
     if (!c->pb || !c->d_pb_val || trials == 0 || bytes < LZX_PB_NT_BYTES) return LZX_OK;   // a stream the caches hold: nothing to choose
     LZX_HIP(hipSetDevice(c->device));
     const bool multi = lzx_exchanges(c);
