@@ -1,6 +1,6 @@
 """tools/ab_lib.py <liblzx.so> <workload> [reps] -- SpMV / loop timing of ONE library build on a synthetic workload, through a minimal
 ctypes binding of its own (so that an older build without the newer entry points can be measured beside the current one on
-the same box: tools/jobs/_r3_job8.sh alternates processes).  GPU box only."""
+the same box: a scratch job script alternates processes).  GPU box only."""
 import ctypes
 import sys
 

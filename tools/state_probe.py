@@ -1,5 +1,5 @@
 """tools/state_probe.py <workload> -- one process: the block -> XCD placement of a few small launches (debug library,
-lzx_dbg_xcc_map) beside the SpMV time of this process.  Run several times in a row (tools/jobs/_r4_job16.sh): does the process
+lzx_dbg_xcc_map) beside the SpMV time of this process.  Run several times in a row (a scratch job script): does the process
 state of the SpMV (NOTES 3.1 i: 3-5 % on C3, 10-20 % on ER, for a process's life) follow where workgroup 0 lands?"""
 import ctypes
 import os
