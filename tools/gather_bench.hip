@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -29,6 +30,18 @@ __global__ void fill_idx(uint32_t *idx, uint64_t count, uint32_t table, int skew
         if (v >= table) v %= table;
     }
     idx[i] = v;
+}
+
+// window-sorted indices: inside every window of W consecutive indices the values ascend over the whole table (roughly uniformly) --
+// the access order of a row-band-major SpMV whose band entries are sorted by column (the uniform family)
+__global__ void fill_idx_sorted(uint32_t *idx, uint64_t count, uint32_t table, uint32_t W)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t j = (uint32_t)(i % W);
+    const double frac = (double)(mix((i + 1) * 0x9E3779B97F4A7C15ull) >> 11) * (1.0 / 9007199254740992.0);
+    uint64_t v = (uint64_t)(((double)j + frac) * (double)table / (double)W);
+    idx[i] = (uint32_t)(v < table ? v : table - 1);
 }
 
 template <int MODE> __device__ __forceinline__ double ld(const double *p)
@@ -62,6 +75,25 @@ __global__ void __launch_bounds__(1024) gather_k(const uint32_t *idx, uint64_t p
     if (acc == 1.2345e-300) out[tid] = acc;  // keep the loads alive
 }
 
+// one workgroup per window (a row band with its y tile in LDS): workgroup b sweeps windows b, b + grid, ... one after the other, its 1024
+// threads reading consecutive packets; all workgroups start together, so on a uniform graph they move over x at the same pace
+__global__ void __launch_bounds__(1024) gather_bands_k(const uint32_t *idx, uint64_t n_windows, uint32_t W, const double *tab, double *out)
+{
+    double acc = 0.0;
+    for (uint64_t w = blockIdx.x; w < n_windows; w += gridDim.x) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(idx + w * W);
+        const uint32_t packets = W / 4;
+        uint32_t q = threadIdx.x;
+        for (; q + 1024 < packets; q += 2048) {
+            const uint4 c0 = p[q], c1 = p[q + 1024];
+            const double x0 = tab[c0.x], x1 = tab[c0.y], x2 = tab[c0.z], x3 = tab[c0.w];
+            const double x4 = tab[c1.x], x5 = tab[c1.y], x6 = tab[c1.z], x7 = tab[c1.w];
+            acc += ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+        }
+    }
+    if (acc == 1.2345e-300) out[blockIdx.x * 1024 + threadIdx.x] = acc;
+}
+
 __global__ void stream_k(const uint4 *p, uint64_t packets, uint32_t *out)
 {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,6 +123,42 @@ int main(int argc, char **argv)
             float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
         }
         printf("index stream only: %.3f ms  %.2f TB/s\n", best, count * 4 / best / 1e9);
+    }
+    if (argc > 1 && !strcmp(argv[1], "er")) {
+        // Erdos-Renyi benchmark graph: x = 10 M doubles (80 MB: beyond the L2s, inside the Infinity Cache), 200 M look-ups per SpMV
+        const uint32_t table = 10000000u;
+        const uint32_t windows[] = {0u, 20480u, 327680u, 2621440u, 20971520u};   // entries of a band of 1 Ki / 16 Ki / 128 Ki / 1 Mi rows at 20 per row
+        for (uint32_t W : windows) {
+            if (W) fill_idx_sorted<<<(unsigned)((count + 255) / 256), 256>>>(idx, count, table, W);
+            else fill_idx<<<(unsigned)((count + 255) / 256), 256>>>(idx, count, table, 0);
+            CHECK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int r = 0; r < 3; ++r) {
+                CHECK(hipEventRecord(a));
+                gather_k<2, 0><<<grid, 1024>>>(idx, count / 4, tab, out);
+                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+            }
+            printf("x = 80 MB, look-ups %s%u: %7.1f G look-ups/s -> 200 M look-ups (one SpMV of the ER graph) take %.2f ms, index stream and sums not counted\n",
+                   W ? "ascending inside windows of " : "in random order, window ", W, count / best / 1e6, 200e6 / (count / best / 1e6) * 1e-6);
+            fflush(stdout);
+            if (W && W <= 2621440u) {   // the same windows, ONE WORKGROUP EACH, 256 / 512 of them sweeping side by side
+                for (int g : {256, 512}) {
+                    const uint64_t n_windows = count / W;
+                    float bb = 1e30f;
+                    for (int r = 0; r < 3; ++r) {
+                        CHECK(hipEventRecord(a));
+                        gather_bands_k<<<g, 1024>>>(idx, n_windows, W, tab, out);
+                        CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                        float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < bb) bb = ms;
+                    }
+                    const double done = (double)n_windows * W;
+                    printf("    one workgroup per window, %d workgroups side by side: %7.1f G look-ups/s -> %.2f ms per 200 M\n", g, done / bb / 1e6, 200e6 / (done / bb / 1e6) * 1e-6);
+                }
+                fflush(stdout);
+            }
+        }
+        return 0;
     }
     const uint64_t tables[] = {4096, 1ull << 17, 1ull << 19, 1ull << 20, 1ull << 22, 10ull << 20, 1ull << 25, 1ull << 27, 1ull << 28};
     for (int skew = 0; skew < 2; ++skew)
