@@ -77,14 +77,19 @@ template <typename T> struct PutArgs {
     u32 cnt[64];
 };
 
+// The polls are RELAXED system-scope loads (they bypass the caches by themselves); the one acquire fence follows the successful
+// poll.  An acquire per poll would invalidate this XCD's L2 every few hundred nanoseconds -- under an SpMV that is running on the
+// other stream at that very moment.
 __device__ __forceinline__ bool spin_until(const unsigned long long *flag, u64 seq, u64 deadline_ticks)
 {
     const u64 t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    bool ok = true;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > deadline_ticks) return false;
+        if (wall_clock64() - t0 > deadline_ticks) { ok = false; break; }
     }
-    return true;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    return ok;
 }
 
 __global__ void __launch_bounds__(64) k_ipc_signal(FlagPeers peers, u32 world, u64 seq)
