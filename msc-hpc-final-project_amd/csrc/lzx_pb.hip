@@ -1081,8 +1081,8 @@ int lzx_pb_place_values(lzx_ctx *c)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes + (4ull << 30)) break;   // never at the price of the caller's memory
         double *fresh = nullptr;
-        // (hipDeviceMallocContiguous is the wrong direction: physically contiguous candidates read 1.76 ms on the Erdos-Renyi
-        //  graph and 0.70 ms on the R-MAT one, against 1.05-1.24 / 0.53-0.55 for ordinary ones)
+        // (other memory types are no way out: hipDeviceMallocContiguous and hipDeviceMallocUncached candidates read 1.76 ms on the
+        //  Erdos-Renyi graph and 0.70 ms on the R-MAT one against 1.05-1.24 / 0.53-0.55; fine-grained ones draw from the same lottery)
         if (hipMalloc(reinterpret_cast<void **>(&fresh), bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         cand[n_cand++] = fresh;
         if (hipMemsetAsync(fresh, 0, bytes, c->stream) != hipSuccess) { (void)hipGetLastError(); break; }
