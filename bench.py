@@ -172,12 +172,18 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return flag.item() == 0.0
 
+    # Sharded hand-over (every rank sweeps the generator in bounded batches and keeps its own rows; same tables bit for bit):
+    # on by default where the whole graph per rank is what hurts -- C5 at N > 1 -- or by LZX_BENCH_SHARDED_INGEST=<sweeps>.
+    shard_opt = int(os.environ.get("LZX_BENCH_SHARDED_INGEST", "1" if (args.workload == "c5" and world > 1) else "0"))
+
     def make_engine(**options):
         """(engine, seconds of graph build), or (None, 0) on EVERY rank when a local step failed on any of them.
         Local steps (handle creation, graph generation + reshaping) and the communicator's creation are guarded and
         agreed on with an all-reduce."""
         if rehearse:
             options = dict(options, exchange_at_world_1=1)
+        if shard_opt:
+            options = dict(options, sharded_ingest=shard_opt)
         e = None
         try:
             e = pkg.Engine(local_rank, **options)
@@ -330,6 +336,7 @@ def main():
                 "exchange_tuning_ms_per_iter": dict(tune) or None,
                 "exchange_chunk0_doubles_per_rank": gi.get("exchange_chunk0", 0),
                 "graph_build_s": round(t_gen, 3),
+                "graph_hand_over": "sharded: each rank sweeps the generator in bounded batches and keeps its own rows" if shard_opt else "whole graph on every rank",
                 # not `value`: the whole k-step decomposition with the host hand-over (x0 upload, basis set-up) and the
                 # download of alpha / beta included -- what a caller holding host buffers sees (rank 0's clock)
                 "iters_per_sec_including_host_transfers": k_cfg / (elapsed + m["t_rest"] + m["t_in"] + m["t_out"]),

@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "liblzx.so")
 DBG_LIB_PATH = os.path.join(_HERE, "liblzx_dbg.so")
 # what the product library's lzx_set_option knows (include/lzx.h); any other option name selects the debug library
 PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "sparse_exchange", "exchange_fp32",
-                   "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32", "reference_order", "placement_trials")
+                   "lazy_normalisation", "timing_marks_every", "reorthogonalise", "basis_fp32", "reference_order", "placement_trials",
+                   "sharded_ingest")
 
 # test-only shapes the product library accepts through lzx_test_set_shape (csrc/lzx_test_hooks.h): they select among code
 # paths the product contains (what large graphs get by themselves), so tests that force them still run liblzx.so
@@ -370,6 +371,21 @@ class LocalGroup:
     def set_graph_csr(self, row_ptr, col_idx):
         for e in self.engines:
             e.set_graph_csr(row_ptr, col_idx)
+        self.n = self.engines[0].n
+
+    def gen_rmat(self, scale, n, draws, seed, a=0.57, b=0.19, c=0.19):
+        for e in self.engines:
+            e.gen_rmat(scale, n, draws, seed, a, b, c)
+        self.n = self.engines[0].n
+
+    def gen_er(self, n, draws, seed):
+        for e in self.engines:
+            e.gen_er(n, draws, seed)
+        self.n = self.engines[0].n
+
+    def set_graph_edges(self, n, src, dst):
+        for e in self.engines:
+            e.set_graph_edges(n, src, dst)
         self.n = self.engines[0].n
 
     def spmv(self, x):

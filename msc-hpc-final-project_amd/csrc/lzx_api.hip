@@ -114,6 +114,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "basis_fp32")) c->qf32_opt = value;
     else if (!strcmp(name, "reference_order")) c->ref_order_opt = value;
     else if (!strcmp(name, "placement_trials")) c->place_opt = value;
+    else if (!strcmp(name, "sharded_ingest")) c->shard_opt = value < 0 ? 0 : value;
 #ifdef LZX_DEBUG_KNOBS
     // experiment knobs and test hooks: only in liblzx_dbg.so (make debug), which tests/ and tools/perf_probe.py load
     // when they ask for one of these; the product library does not know the names

@@ -17,6 +17,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <string>
 
 #include "lzx_internal.h"
 
@@ -43,6 +44,9 @@ int lzx_graph_release(lzx_ctx *c)
 
     dev_free(c->d_row_ptr);
     dev_free(c->d_col_idx);
+    dev_free(c->d_shard_deg);
+    c->shard = lzx_ctx::lzx_key_source();
+    c->sharded = false;
     dev_free(c->d_gidx_of_old);
     dev_free(c->d_sx_send_idx);
     dev_free(c->d_sx_sendbuf);
@@ -352,6 +356,363 @@ k_fill_long_hub(const u64 *row_ptr, const u32 *col_idx, const u32 *code_of_old, 
     for (u64 k = out + lane; k < end; k += 64) long_cols[k] = (uint16_t)pad_code;
 }
 
+
+// ==================================================================================================================
+// Sharded hand-over (option sharded_ingest; SURVEY.md 7.1 step 7, the loader of parallel-final/lib/adjMatrix.cc:21-46 for
+// graphs a single device need not hold).  The whole-graph hand-over sorts all 2 m directed keys at once and leaves the
+// whole CSR on every rank (C5: 32 GB of keys, twice more for the sort, then 17 GB of CSR -- per rank).  Here a rank never
+// holds more than one bounded batch of keys besides ITS OWN rows:
+//   sweep 1  degrees: for each of B key classes (row % B) the source is re-drawn, the class's keys sorted and
+//            de-duplicated, and the run lengths are the degrees of the class's vertices;
+//   sweep 2  (blocked mode) the same over the keys whose column is one of the staged top-degree vertices: the count that
+//            breaks ties of the degree ranking (k_staged_key);
+//   sweep 3  rows: for contiguous vertex ranges, the keys whose row this rank OWNS under the final ranking, sorted and
+//            de-duplicated straight into its col_idx.
+// Nothing is exchanged: every rank re-draws the same seeded source (or sweeps the same edge list), so all ranks compute
+// the same degrees and the same ranking without talking, exactly as they do from a whole graph.  The resulting tables are
+// those of the whole-graph hand-over entry for entry (tests/test_gpu_sharded.py compares SpMV and Lanczos bits).
+// The sparse second exchange chunk derives its send lists from the rank's own rows through the matrix's symmetry.
+__device__ __forceinline__ u64 gen_word(u64 seed, u64 ctr)
+{
+    u64 z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// draw e of the seeded generators (integer specification: oracle/lanczos_oracle.c, orc_gen_er_keys / orc_gen_rmat_keys)
+__device__ __forceinline__ bool gen_draw(int kind, u32 scale, u64 n, u64 seed, u32 ta, u32 tab, u32 tabc, u64 e, u64 &u, u64 &v)
+{
+    if (kind == 0) {
+        u = ((gen_word(seed, 2 * e) >> 32) * n) >> 32;
+        v = ((gen_word(seed, 2 * e + 1) >> 32) * n) >> 32;
+        return u != v;
+    }
+    for (u32 t = 0; t < 8; ++t) {
+        u64 w = 0;
+        u = 0; v = 0;
+        for (u32 l = 0; l < scale; ++l) {
+            if ((l & 3) == 0) w = gen_word(seed, (e * 8 + t) * 8 + (l >> 2));
+            const u32 r = (u32)(w & 0xffff);
+            w >>= 16;
+            const u32 ub = r >= tab;
+            const u32 vb = (r >= ta && r < tab) || r >= tabc;
+            u = (u << 1) | ub;
+            v = (v << 1) | vb;
+        }
+        if (u < n && v < n) return u != v;
+    }
+    return false;
+}
+
+struct ShardFilter {
+    int mode = 0;              // 0: row % mod == cls;  1: that, and the column is staged (rank < hub);  2: lo <= row < hi and the row is mine
+    u32 mod = 1, cls = 0;
+    const u32 *rank_of_old = nullptr;
+    u32 hub = 0;
+    u64 lo = 0, hi = 0;
+    const u32 *gidx_of_old = nullptr;
+    u32 n_loc_pad = 1, me = 0;
+};
+
+__device__ __forceinline__ bool shard_pass(const ShardFilter &f, u64 row, u64 col)
+{
+    if (f.mode == 2) return row >= f.lo && row < f.hi && f.gidx_of_old[row] / f.n_loc_pad == f.me;
+    if (row % f.mod != f.cls) return false;
+    return f.mode == 0 || f.rank_of_old[col] < f.hub;
+}
+
+// The directed keys of the source that pass the filter, appended in no particular order (they are sorted next).  out ==
+// nullptr: count only.  One atomic per wavefront and round.
+__global__ void __launch_bounds__(256)
+k_shard_emit(lzx_ctx::lzx_key_source s, ShardFilter f, u64 *out, unsigned long long *count)
+{
+    const u64 total = s.kind == 2 ? s.m : s.draws;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u32 lane = threadIdx.x & 63;
+    unsigned long long mine = 0;
+    for (u64 e0 = (u64)blockIdx.x * blockDim.x; e0 < total; e0 += stride) {
+        const u64 e = e0 + threadIdx.x;
+        u64 u = 0, v = 0;
+        bool ok = false;
+        if (e < total) {
+            if (s.kind == 2) {
+                u = s.d_src[e]; v = s.d_dst[e];
+                ok = true;                      // endpoints were range-checked when the list was uploaded
+            } else {
+                ok = gen_draw(s.kind, s.scale, s.n, s.seed, s.ta, s.tab, s.tabc, e, u, v);
+            }
+        }
+        // a self loop (edge lists only) is ONE diagonal entry, as in the std::set build
+        const bool k0 = ok && shard_pass(f, u, v), k1 = ok && u != v && shard_pass(f, v, u);
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        const u32 n0 = (u32)__popcll(m0), n1 = (u32)__popcll(m1);
+        if (!out) { if (lane == 0) mine += n0 + n1; continue; }
+        if (n0 + n1 == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)(n0 + n1));
+        base = __shfl(base, 0, 64);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (k0) out[base + __popcll(m0 & below)] = (u << 32) | v;
+        if (k1) out[base + n0 + __popcll(m1 & below)] = (v << 32) | u;
+    }
+    if (!out && lane == 0 && mine) atomicAdd(count, mine);
+}
+
+// sorted unique keys: every row is one run; its length goes to out[row] (two atomics per row, none contended)
+__global__ void k_shard_run_lengths(const u64 *keys, u64 cnt, u32 *out)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const u32 row = (u32)(keys[i] >> 32);
+    if (i == 0 || (u32)(keys[i - 1] >> 32) != row) atomicSub(&out[row], (u32)i);
+    if (i + 1 == cnt || (u32)(keys[i + 1] >> 32) != row) atomicAdd(&out[row], (u32)(i + 1));
+}
+
+__global__ void k_shard_cols(const u64 *keys, u64 cnt, u32 *col_idx)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) col_idx[i] = (u32)(keys[i] & 0xffffffffu);
+}
+
+__global__ void k_shard_owned_deg(const u32 *deg, const u32 *gidx_of_old, u32 n_loc_pad, u32 me, u64 n, u64 *out)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gidx_of_old[i] / n_loc_pad == me ? deg[i] : 0u;
+    if (i == n) out[i] = 0;
+}
+
+__global__ void k_shard_sum_deg(const u32 *deg, u64 n, unsigned long long *total)
+{
+    const u64 nthreads = (u64)gridDim.x * blockDim.x;
+    unsigned long long s = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) s += deg[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+}
+
+__global__ void k_shard_iota(u32 *ids, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ids[i] = (u32)i;
+}
+
+// first vertex whose row_ptr reaches target[j]
+__global__ void k_shard_bounds(const u64 *row_ptr, u64 n, const u64 *target, u32 count, u64 *bound)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (row_ptr[mid] < target[j]) lo = mid + 1; else hi = mid;
+    }
+    bound[j] = lo;
+}
+
+// k_staged_key with the staged-column counts already known per vertex (sharded hand-over, sweep 2)
+__global__ void k_staged_key_counted(const u32 *sorted_ids, const u32 *sorted_deg, const u32 *staged_of_old, u64 n_active, u64 n,
+                                     u32 hub, int count_major, u64 *key)
+{
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u32 d = sorted_deg[r];
+    if (r < hub) { key[r] = count_major ? ~(u64)r : ((u64)d << 32) | (0xffffffffu - (u32)r); return; }
+    const u32 low = r < n_active ? staged_of_old[sorted_ids[r]] : 0u;
+    key[r] = count_major ? ((u64)low << 32) | d : ((u64)d << 32) | low;
+}
+
+// k_sx_mark from this rank's rows alone: `ref` as there; `want` through the symmetry of the matrix -- a row of rank p has an
+// entry in my column v exactly when my row v has an entry in a column that rank p owns.
+__global__ void __launch_bounds__(64)
+k_sx_mark_own(const u64 *row_ptr, const u32 *col_idx, const u32 *sorted_ids, const u32 *code_of_old, const u32 *gidx_of_old,
+              u64 n_active, u32 world, u32 me, u32 hub, u32 xs0, u32 L1, u32 n_loc_pad, uint8_t *ref, uint8_t *want)
+{
+    const u32 lane = threadIdx.x;
+    const u32 c1 = hub + world * xs0;
+    for (u64 l = blockIdx.x; l * world + me < n_active; l += gridDim.x) {
+        const u32 o = sorted_ids[l * world + me];
+        const u32 own = code_of_old[o];
+        const bool in_chunk1 = own >= c1;
+        const u32 my_l = in_chunk1 ? (own - c1) % L1 : 0u;
+        const u64 beg = row_ptr[o], end = row_ptr[o + 1];
+        for (u64 k = beg + lane; k < end; k += 64) {
+            const u32 col = col_idx[k];
+            const u32 code = code_of_old[col];
+            if (code >= c1) ref[code - c1] = 1;
+            if (in_chunk1) want[(size_t)(gidx_of_old[col] / n_loc_pad) * L1 + my_l] = 1;
+        }
+    }
+}
+
+// Sorts d_keys[nkeys] and drops duplicates.  Consumes (frees) d_keys; on success *d_uniq (caller frees) holds *cnt keys.
+static int sorted_unique_keys(lzx_ctx *c, u64 *d_keys, u64 nkeys, u64 **d_uniq_out, u64 *cnt_out)
+{
+    hipStream_t st = c->stream;
+    u64 *d_sorted = nullptr, *d_uniq = nullptr, *d_count = nullptr;
+    void *d_tmp = nullptr;
+    int rc = LZX_OK;
+    *d_uniq_out = nullptr;
+    *cnt_out = 0;
+    auto cleanup = [&]() {
+        dev_free(d_keys); dev_free(d_sorted); dev_free(d_uniq); dev_free(d_count);
+        if (d_tmp) (void)hipFree(d_tmp);
+        d_tmp = nullptr;
+    };
+#define SUK(call) do { rc = (call); if (rc != LZX_OK) { cleanup(); return rc; } } while (0)
+#define SUK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        lzx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); \
+        return e_ == hipErrorOutOfMemory ? LZX_ERR_NOMEM : LZX_ERR_HIP; } } while (0)
+    // one work-item per key below, and a launch holds at most 2^32 of them
+    if (nkeys >= (1ull << 32) - (1ull << 24)) { cleanup(); LZX_FAIL(LZX_ERR_LIMIT, "edge list too long for one ingest (%llu directed entries)", (unsigned long long)nkeys); }
+    SUK(dev_alloc(&d_sorted, nkeys)); SUK(dev_alloc(&d_count, 1));
+    size_t tb = 0;
+    SUK_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_keys, d_sorted, (u64)nkeys, 0, 64, st));
+    SUK_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
+    SUK_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_keys, d_sorted, (u64)nkeys, 0, 64, st));
+    SUK_HIP(hipStreamSynchronize(st));
+    (void)hipFree(d_tmp); d_tmp = nullptr;
+    dev_free(d_keys);
+    SUK(dev_alloc(&d_uniq, nkeys));
+    tb = 0;
+    SUK_HIP(hipcub::DeviceSelect::Unique(nullptr, tb, d_sorted, d_uniq, d_count, (u64)nkeys, st));
+    SUK_HIP(hipMalloc(&d_tmp, tb ? tb : 16));
+    SUK_HIP(hipcub::DeviceSelect::Unique(d_tmp, tb, d_sorted, d_uniq, d_count, (u64)nkeys, st));
+    u64 cnt = 0;
+    SUK_HIP(hipMemcpyAsync(&cnt, d_count, sizeof(u64), hipMemcpyDeviceToHost, st));
+    SUK_HIP(hipStreamSynchronize(st));
+    *d_uniq_out = d_uniq;
+    *cnt_out = cnt;
+    d_uniq = nullptr;
+    cleanup();
+#undef SUK
+#undef SUK_HIP
+    return LZX_OK;
+}
+
+static const u64 LZX_SHARD_BATCH = 1ull << 28;   // directed keys per sweep batch when the option leaves the choice here (2 GiB; about 8 GiB with the sort's buffers)
+
+// One batch of a sweep: the filtered keys of the source, sorted, unique.  *d_uniq is null when the batch is empty.
+static int shard_batch(lzx_ctx *c, const ShardFilter &f, u64 **d_uniq, u64 *cnt)
+{
+    hipStream_t st = c->stream;
+    *d_uniq = nullptr;
+    *cnt = 0;
+    const u64 total = c->shard.kind == 2 ? c->shard.m : c->shard.draws;
+    if (total == 0) return LZX_OK;
+    unsigned long long *d_cnt = nullptr, h_cnt = 0;
+    LZX_TRY(dev_alloc(&d_cnt, 1));
+    const u32 grid = (u32)std::min<u64>((total + 255) / 256, (u64)c->cu_count * 32);
+    hipError_t e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_shard_emit, dim3(grid), dim3(256), 0, st, c->shard, f, (u64 *)nullptr, d_cnt);
+        e = hipMemcpyAsync(&h_cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { dev_free(d_cnt); LZX_FAIL(LZX_ERR_HIP, "sharded hand-over, count pass: %s", hipGetErrorString(e)); }
+    if (h_cnt == 0) { dev_free(d_cnt); return LZX_OK; }
+    u64 *d_keys = nullptr;
+    if (dev_alloc(&d_keys, h_cnt) != LZX_OK) { dev_free(d_cnt); return LZX_ERR_NOMEM; }
+    unsigned long long h_cnt2 = 0;
+    e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_shard_emit, dim3(grid), dim3(256), 0, st, c->shard, f, d_keys, d_cnt);
+        e = hipMemcpyAsync(&h_cnt2, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    dev_free(d_cnt);
+    if (e != hipSuccess) { dev_free(d_keys); LZX_FAIL(LZX_ERR_HIP, "sharded hand-over, fill pass: %s", hipGetErrorString(e)); }
+    if (h_cnt2 != h_cnt) { dev_free(d_keys); LZX_FAIL(LZX_ERR_STATE, "sharded hand-over: the source gave %llu keys, then %llu", h_cnt, h_cnt2); }
+    return sorted_unique_keys(c, d_keys, h_cnt, d_uniq, cnt);
+}
+
+static u32 shard_classes(const lzx_ctx *c)
+{
+    if (c->shard_opt >= 2) return (u32)std::min<int64_t>(c->shard_opt, 4096);
+    const u64 total = 2 * (c->shard.kind == 2 ? c->shard.m : c->shard.draws);
+    return (u32)std::max<u64>(1, (total + LZX_SHARD_BATCH - 1) / LZX_SHARD_BATCH);
+}
+
+// Sweeps 1 and 2: d_out[v] (zeroed here) = number of distinct entries of row v (mode 0), or of those whose column is staged (mode 1).
+static int shard_count_sweep(lzx_ctx *c, int mode, const u32 *d_rank_of_old, u32 hub, u32 *d_out)
+{
+    LZX_HIP(hipMemsetAsync(d_out, 0, sizeof(u32) * c->n, c->stream));
+    const u32 classes = shard_classes(c);
+    for (u32 cls = 0; cls < classes; ++cls) {
+        ShardFilter f;
+        f.mode = mode; f.mod = classes; f.cls = cls; f.rank_of_old = d_rank_of_old; f.hub = hub;
+        u64 *d_uniq = nullptr, cnt = 0;
+        LZX_TRY(shard_batch(c, f, &d_uniq, &cnt));
+        if (cnt) hipLaunchKernelGGL(k_shard_run_lengths, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, c->stream, d_uniq, cnt, d_out);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        dev_free(d_uniq);
+        if (e != hipSuccess) LZX_FAIL(LZX_ERR_HIP, "sharded hand-over, degree sweep: %s", hipGetErrorString(e));
+    }
+    return LZX_OK;
+}
+
+// Sweep 3: this rank's rows.  d_row_ptr[n + 1] over ALL vertices (a row of another rank is empty), d_col_idx = own entries.
+static int shard_build_rows(lzx_ctx *c)
+{
+    hipStream_t st = c->stream;
+    const u64 n = c->n;
+    LZX_TRY(dev_alloc(&c->d_row_ptr, n + 1));
+    hipLaunchKernelGGL(k_shard_owned_deg, dim3((u32)((n + 256) / 256)), dim3(256), 0, st, c->d_shard_deg, c->d_gidx_of_old, c->n_loc_pad,
+                       (u32)c->rank, n, c->d_row_ptr);
+    {
+        size_t sb = 0;
+        void *tmp = nullptr;
+        LZX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, c->d_row_ptr, c->d_row_ptr, n + 1, st));
+        LZX_HIP(hipMalloc(&tmp, sb ? sb : 16));
+        hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, sb, c->d_row_ptr, c->d_row_ptr, n + 1, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        LZX_HIP(e);
+    }
+    u64 own = 0;
+    LZX_HIP(hipMemcpy(&own, c->d_row_ptr + n, sizeof(u64), hipMemcpyDeviceToHost));
+    if (own >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "%llu entries in this rank's rows: use more ranks (limit 2^32 per rank)", (unsigned long long)own);
+    LZX_TRY(dev_alloc(&c->d_col_idx, own));
+    if (own == 0) return LZX_OK;
+    // vertex ranges holding about equal shares of the rank's entries
+    u32 blocks = c->shard_opt >= 2 ? (u32)std::min<int64_t>(c->shard_opt, 4096) : (u32)std::max<u64>(1, (own + LZX_SHARD_BATCH / 2 - 1) / (LZX_SHARD_BATCH / 2));
+    std::vector<u64> target(blocks + 1), bound(blocks + 1), at(blocks + 1);
+    for (u32 j = 0; j <= blocks; ++j) target[j] = own / blocks * j;
+    target[blocks] = own;
+    u64 *d_t = nullptr, *d_b = nullptr;
+    LZX_TRY(dev_alloc(&d_t, blocks + 1));
+    if (dev_alloc(&d_b, blocks + 1) != LZX_OK) { dev_free(d_t); return LZX_ERR_NOMEM; }
+    hipError_t e = hipMemcpyAsync(d_t, target.data(), sizeof(u64) * (blocks + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_shard_bounds, dim3((blocks + 64) / 64), dim3(64), 0, st, c->d_row_ptr, n, d_t, blocks + 1, d_b);
+        e = hipMemcpyAsync(bound.data(), d_b, sizeof(u64) * (blocks + 1), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    dev_free(d_t); dev_free(d_b);
+    LZX_HIP(e);
+    bound[0] = 0;
+    bound[blocks] = n;
+    for (u32 j = 0; j <= blocks; ++j)
+        LZX_HIP(hipMemcpy(&at[j], c->d_row_ptr + bound[j], sizeof(u64), hipMemcpyDeviceToHost));
+    for (u32 j = 0; j < blocks; ++j) {
+        if (bound[j + 1] <= bound[j]) continue;
+        ShardFilter f;
+        f.mode = 2; f.lo = bound[j]; f.hi = bound[j + 1]; f.gidx_of_old = c->d_gidx_of_old; f.n_loc_pad = c->n_loc_pad; f.me = (u32)c->rank;
+        u64 *d_uniq = nullptr, cnt = 0;
+        LZX_TRY(shard_batch(c, f, &d_uniq, &cnt));
+        if (cnt != at[j + 1] - at[j]) {
+            dev_free(d_uniq);
+            LZX_FAIL(LZX_ERR_STATE, "sharded hand-over: vertices %llu..%llu hold %llu entries of this rank where the degree sweep counted %llu",
+                     (unsigned long long)bound[j], (unsigned long long)bound[j + 1], (unsigned long long)cnt, (unsigned long long)(at[j + 1] - at[j]));
+        }
+        if (cnt) hipLaunchKernelGGL(k_shard_cols, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, st, d_uniq, cnt, c->d_col_idx + at[j]);
+        e = hipStreamSynchronize(st);
+        dev_free(d_uniq);
+        LZX_HIP(e);
+    }
+    return LZX_OK;
+}
+
 static u32 round_up(u32 a, u32 m) { return (a + m - 1) / m * m; }
 
 int lzx_graph_prepare(lzx_ctx *c)
@@ -415,7 +776,13 @@ int lzx_graph_prepare(lzx_ctx *c)
     PREP(dev_alloc(&d_code, n));
     PREP(dev_alloc(&c->d_gidx_of_old, n));
     const u32 gb = (u32)((n + 255) / 256);
-    hipLaunchKernelGGL(k_degrees, dim3(gb), dim3(256), 0, st, c->d_row_ptr, d_deg, d_ids, n);
+    const bool sharded = c->shard.kind >= 0;   // sharded hand-over: no CSR yet -- degrees were counted by its first sweep
+    if (sharded) {
+        PREP_HIP(hipMemcpyAsync(d_deg, c->d_shard_deg, sizeof(u32) * n, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_shard_iota, dim3(gb), dim3(256), 0, st, d_ids, n);
+    } else {
+        hipLaunchKernelGGL(k_degrees, dim3(gb), dim3(256), 0, st, c->d_row_ptr, d_deg, d_ids, n);
+    }
     size_t tmp_bytes = 0;
     PREP_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, d_deg, d_sdeg, d_ids, d_sids,
                                                          (u64)n, 0, 32, st));
@@ -504,8 +871,15 @@ int lzx_graph_prepare(lzx_ctx *c)
         if (rc == LZX_OK) rc = dev_alloc(&d_skey, n);
         if (rc != LZX_OK) { dev_free(d_key); dev_free(d_skey); cleanup(); return rc; }
         hipLaunchKernelGGL(k_rank_of_old, dim3(gb), dim3(256), 0, st, d_sids, d_code, n);
-        hipLaunchKernelGGL(k_staged_key, dim3((u32)std::min<u64>(n, 1u << 20)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_sids,
-                           d_sdeg, d_code, c->n_active, n, c->hub_real, c->tie_sort_opt == 2 ? 1 : 0, d_key);
+        if (sharded) {   // sweep 2: every vertex's count of staged columns, d_ids (free until the sort below) as the scratch
+            rc = shard_count_sweep(c, 1, d_code, c->hub_real, d_ids);
+            if (rc != LZX_OK) { dev_free(d_key); dev_free(d_skey); cleanup(); return rc; }
+            hipLaunchKernelGGL(k_staged_key_counted, dim3(gb), dim3(256), 0, st, d_sids, d_sdeg, d_ids, c->n_active, n, c->hub_real,
+                               c->tie_sort_opt == 2 ? 1 : 0, d_key);
+        } else {
+            hipLaunchKernelGGL(k_staged_key, dim3((u32)std::min<u64>(n, 1u << 20)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx, d_sids,
+                               d_sdeg, d_code, c->n_active, n, c->hub_real, c->tie_sort_opt == 2 ? 1 : 0, d_key);
+        }
         size_t tb = 0;
         hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, d_key, d_skey, d_sids, d_ids, (u64)n, 0, 64, st);
         if (e == hipSuccess && tb > tmp_bytes) {
@@ -526,6 +900,10 @@ int lzx_graph_prepare(lzx_ctx *c)
     const u32 sentinel = pb ? c->hub_real : c->hub + (u32)((u64)world * c->xs);
     hipLaunchKernelGGL(k_rank_maps, dim3(gb), dim3(256), 0, st, d_sids, c->d_gidx_of_old, d_code, n,
                        world, c->n_loc_pad, c->xs, c->xs0, c->hub_real);
+    if (sharded) {   // sweep 3: the ranking is final, so ownership is: this rank's rows become its CSR
+        PREP_HIP(hipStreamSynchronize(st));
+        PREP(shard_build_rows(c));
+    }
 
     // ---- 1b. sparse exchange of chunk 1: this rank's packed x layout and its send lists (see k_sx_mark) ----
     c->sparse = false;
@@ -543,8 +921,12 @@ int lzx_graph_prepare(lzx_ctx *c)
         SX(dev_alloc(&d_w32, cnt + 1)); SX(dev_alloc(&d_pos, cnt + 1)); SX(dev_alloc(&d_spos, cnt + 1));
         SX_HIP(hipMemsetAsync(d_ref, 0, cnt, st));
         SX_HIP(hipMemsetAsync(d_want, 0, cnt, st));
-        hipLaunchKernelGGL(k_sx_mark, dim3((u32)std::min<u64>(std::max<u64>(c->n_active, 1), 1u << 20)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx,
-                           d_sids, d_code, c->n_active, world, rank, c->hub_real, c->xs0, L1, d_ref, d_want);
+        if (sharded && world > 1)
+            hipLaunchKernelGGL(k_sx_mark_own, dim3((u32)std::min<u64>(std::max<u64>(c->n_active / world + 1, 1), 1u << 20)), dim3(64), 0, st, c->d_row_ptr,
+                               c->d_col_idx, d_sids, d_code, c->d_gidx_of_old, c->n_active, world, rank, c->hub_real, c->xs0, L1, c->n_loc_pad, d_ref, d_want);
+        else
+            hipLaunchKernelGGL(k_sx_mark, dim3((u32)std::min<u64>(std::max<u64>(c->n_active, 1), 1u << 20)), dim3(64), 0, st, c->d_row_ptr, c->d_col_idx,
+                               d_sids, d_code, c->n_active, world, rank, c->hub_real, c->xs0, L1, d_ref, d_want);
         auto scan = [&](const uint8_t *flags, u32 *out) -> int {
             hipLaunchKernelGGL(k_widen_u8, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, st, flags, cnt, d_w32);
             LZX_HIP(hipMemsetAsync(d_w32 + cnt, 0, sizeof(u32), st));
@@ -892,14 +1274,6 @@ __global__ void k_edges_to_keys(const u32 *src, const u32 *dst, u64 m, u64 n, u6
     keys[2 * e + 1] = ok && u != v ? ((v << 32) | u) : ~0ull;
 }
 
-__device__ __forceinline__ u64 gen_word(u64 seed, u64 ctr)
-{
-    u64 z = seed + (ctr + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 // oracle/lanczos_oracle.c: orc_gen_er_keys / orc_gen_rmat_keys, one thread per draw.
 __global__ void k_gen_keys(int kind, u32 scale, u64 n, u64 draws, u64 seed, u32 ta, u32 tab, u32 tabc,
                            u64 *keys)
@@ -907,29 +1281,55 @@ __global__ void k_gen_keys(int kind, u32 scale, u64 n, u64 draws, u64 seed, u32 
     const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= draws) return;
     u64 u = 0, v = 0;
-    bool ok = false;
-    if (kind == 0) {
-        u = ((gen_word(seed, 2 * e) >> 32) * n) >> 32;
-        v = ((gen_word(seed, 2 * e + 1) >> 32) * n) >> 32;
-        ok = (u != v);
-    } else {
-        for (u32 t = 0; t < 8; ++t) {
-            u64 w = 0;
-            u = 0; v = 0;
-            for (u32 l = 0; l < scale; ++l) {
-                if ((l & 3) == 0) w = gen_word(seed, (e * 8 + t) * 8 + (l >> 2));
-                const u32 r = (u32)(w & 0xffff);
-                w >>= 16;
-                const u32 ub = r >= tab;
-                const u32 vb = (r >= ta && r < tab) || r >= tabc;
-                u = (u << 1) | ub;
-                v = (v << 1) | vb;
-            }
-            if (u < n && v < n) { ok = (u != v); break; }
-        }
-    }
+    const bool ok = gen_draw(kind, scale, n, seed, ta, tab, tabc, e, u, v);
     keys[2 * e] = ok ? ((u << 32) | v) : ~0ull;
     keys[2 * e + 1] = ok ? ((v << 32) | u) : ~0ull;
+}
+
+// The sharded hand-over itself: sweep 1 here (the reshaping needs the entry count before it starts), sweeps 2 and 3 inside
+// lzx_graph_prepare, at the points where the whole-graph hand-over reads the CSR.  `src` is valid during this call only.
+static int shard_handover(lzx_ctx *c, const lzx_ctx::lzx_key_source &src)
+{
+    lzx_graph_release(c);
+    c->n = src.n;
+    c->shard = src;
+    int rc = dev_alloc(&c->d_shard_deg, src.n);
+    if (rc == LZX_OK) rc = shard_count_sweep(c, 0, nullptr, 0, c->d_shard_deg);
+    if (rc == LZX_OK) {
+        unsigned long long *d_tot = nullptr, tot = 0;
+        rc = dev_alloc(&d_tot, 1);
+        if (rc == LZX_OK) {
+            hipError_t e = hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), c->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_shard_sum_deg, dim3(1024), dim3(256), 0, c->stream, c->d_shard_deg, src.n, d_tot);
+                e = hipMemcpyAsync(&tot, d_tot, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            dev_free(d_tot);
+            if (e != hipSuccess) { lzx_set_error("sharded hand-over: %s", hipGetErrorString(e)); rc = LZX_ERR_HIP; }
+            c->nnz = tot;
+        }
+    }
+    if (rc == LZX_OK) rc = lzx_graph_prepare(c);
+    c->shard = lzx_ctx::lzx_key_source();
+    dev_free(c->d_shard_deg);
+    if (rc != LZX_OK) {
+        const std::string msg = lzx_last_error();   // the release below must not lose the reason
+        lzx_graph_release(c);
+        lzx_set_error("%s", msg.c_str());
+        return rc;
+    }
+    c->sharded = c->world > 1;   // at one rank the CSR on the device is the whole graph after all
+    return LZX_OK;
+}
+
+// sharded hand-over of an edge list: the range check alone (the keys are formed batch by batch later)
+__global__ void k_check_endpoints(const u32 *src, const u32 *dst, u64 m, u64 n, u32 *bad)
+{
+    const u64 nthreads = (u64)gridDim.x * blockDim.x;
+    bool b = false;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += nthreads) b |= src[e] >= n || dst[e] >= n;
+    if (b) bad[0] = 1u;
 }
 
 extern "C" int lzx_set_graph_edges(lzx_handle c, uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst)
@@ -937,11 +1337,12 @@ extern "C" int lzx_set_graph_edges(lzx_handle c, uint64_t n, uint64_t m, const u
     if (!c || (m && (!src || !dst)) || n == 0) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_edges: bad argument");
     lzx_agree_guard guard(c);   // RCCL: a local failure below still votes at the hand-over's sync point (lzx_internal.h)
     LZX_HIP(hipSetDevice(c->device));
+    const bool shard = c->shard_opt > 0;   // the endpoint pairs stay resident (8 bytes per edge) and are swept; the 2 m keys are never formed at once
     u32 *d_src = nullptr, *d_dst = nullptr, *d_bad = nullptr, bad = 0;
     u64 *d_keys = nullptr;
     LZX_TRY(dev_alloc(&d_src, m));
     if (dev_alloc(&d_dst, m) != LZX_OK) { dev_free(d_src); return LZX_ERR_NOMEM; }
-    if (dev_alloc(&d_keys, 2 * m) != LZX_OK) { dev_free(d_src); dev_free(d_dst); return LZX_ERR_NOMEM; }
+    if (!shard && dev_alloc(&d_keys, 2 * m) != LZX_OK) { dev_free(d_src); dev_free(d_dst); return LZX_ERR_NOMEM; }
     if (dev_alloc(&d_bad, 1) != LZX_OK) { dev_free(d_src); dev_free(d_dst); dev_free(d_keys); return LZX_ERR_NOMEM; }
     hipError_t e = hipSuccess;
     if (m) {
@@ -949,14 +1350,23 @@ extern "C" int lzx_set_graph_edges(lzx_handle c, uint64_t n, uint64_t m, const u
         if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst, sizeof(u32) * m, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), c->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_edges_to_keys, dim3((u32)((m + 255) / 256)), dim3(256), 0, c->stream, d_src, d_dst, m, n, d_keys, d_bad);
+            if (shard) hipLaunchKernelGGL(k_check_endpoints, dim3(1024), dim3(256), 0, c->stream, d_src, d_dst, m, n, d_bad);
+            else hipLaunchKernelGGL(k_edges_to_keys, dim3((u32)((m + 255) / 256)), dim3(256), 0, c->stream, d_src, d_dst, m, n, d_keys, d_bad);
             e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
     }
-    dev_free(d_src); dev_free(d_dst); dev_free(d_bad);
-    if (e != hipSuccess) { dev_free(d_keys); LZX_FAIL(LZX_ERR_HIP, "edge upload: %s", hipGetErrorString(e)); }
-    if (bad) { dev_free(d_keys); LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_edges: an endpoint is >= n"); }
+    dev_free(d_bad);
+    int rc = LZX_OK;
+    if (e != hipSuccess) { lzx_set_error("edge upload: %s", hipGetErrorString(e)); rc = LZX_ERR_HIP; }
+    else if (bad) { lzx_set_error("lzx_set_graph_edges: an endpoint is >= n"); rc = LZX_ERR_ARG; }
+    else if (shard) {
+        lzx_ctx::lzx_key_source ks;
+        ks.kind = 2; ks.n = n; ks.d_src = d_src; ks.d_dst = d_dst; ks.m = m;
+        rc = shard_handover(c, ks);
+    }
+    dev_free(d_src); dev_free(d_dst);
+    if (rc != LZX_OK || shard) { dev_free(d_keys); return rc; }
     return csr_from_keys_dev(c, n, d_keys, 2 * m);
 }
 
@@ -967,6 +1377,11 @@ extern "C" int lzx_gen_graph(lzx_handle c, int kind, uint32_t scale, uint64_t n,
     if (kind == 1 && (scale == 0 || scale > 32 || n > (1ull << scale))) LZX_FAIL(LZX_ERR_ARG, "lzx_gen_graph: scale/n mismatch");
     lzx_agree_guard guard(c);   // RCCL: a local failure below still votes at the hand-over's sync point (lzx_internal.h)
     LZX_HIP(hipSetDevice(c->device));
+    if (c->shard_opt > 0) {
+        lzx_ctx::lzx_key_source ks;
+        ks.kind = kind; ks.scale = scale; ks.n = n; ks.draws = draws; ks.seed = seed; ks.ta = ta; ks.tab = tab; ks.tabc = tabc;
+        return shard_handover(c, ks);
+    }
     u64 *d_keys = nullptr;
     LZX_TRY(dev_alloc(&d_keys, 2 * draws));
     if (draws) {
@@ -1040,6 +1455,7 @@ extern "C" int lzx_get_graph_csr(lzx_handle c, uint64_t *row_ptr, uint32_t *col_
 {
     if (!c || !row_ptr || !col_idx) LZX_FAIL(LZX_ERR_ARG, "lzx_get_graph_csr: bad argument");
     if (!c->d_row_ptr) LZX_FAIL(LZX_ERR_STATE, "no graph set");
+    if (c->sharded) LZX_FAIL(LZX_ERR_STATE, "lzx_get_graph_csr: the graph came through the sharded hand-over -- no rank holds all of it");
     LZX_HIP(hipSetDevice(c->device));
     LZX_HIP(hipMemcpy(row_ptr, c->d_row_ptr, sizeof(u64) * (c->n + 1), hipMemcpyDeviceToHost));
     if (c->nnz) LZX_HIP(hipMemcpy(col_idx, c->d_col_idx, sizeof(u32) * c->nnz, hipMemcpyDeviceToHost));

@@ -118,9 +118,24 @@ struct lzx_ctx {
     bool agree_pending = false;        // RCCL: a graph hand-over is under way and has not yet cast its vote at the sync point (lzx_agree_guard)
 
     // ---- whole graph, caller's vertex order (device) ----
+    // (option sharded_ingest, several ranks: d_row_ptr still has n + 1 entries, but the rows of OTHER ranks are empty and
+    //  d_col_idx holds this rank's rows only; nnz stays the whole matrix's count)
     u64 n = 0, nnz = 0, max_degree = 0;
     u64 *d_row_ptr = nullptr;
     u32 *d_col_idx = nullptr;
+    // Sharded hand-over (lzx_graph.hip, "sharded hand-over"): where the directed entries come from while the hand-over runs
+    // -- a seeded generator or an edge list resident on the device -- and every vertex's degree, counted in bounded sweeps
+    // before lzx_graph_prepare starts.  Both live only for the duration of the entry point.
+    struct lzx_key_source {
+        int kind = -1;                 // -1: none (whole-graph hand-over); 0 Erdos-Renyi, 1 R-MAT (lzx_gen_graph); 2 edge list
+        u32 scale = 0, ta = 0, tab = 0, tabc = 0;
+        u64 n = 0, draws = 0, seed = 0;
+        const u32 *d_src = nullptr, *d_dst = nullptr;   // kind 2: m endpoint pairs
+        u64 m = 0;
+    } shard;
+    u32 *d_shard_deg = nullptr;        // [n] degree of every vertex, caller's order
+    bool sharded = false;              // the graph on this handle came through the sharded hand-over
+    int64_t shard_opt = 0;             // option sharded_ingest: 0 off, 1 on (sweeps sized automatically), >= 2 on with that many sweeps
 
     // ---- this rank's share, internal order ----
     u32 n_loc_real = 0;                // rows owned
@@ -316,7 +331,7 @@ struct lzx_ctx {
 
 // ---- lzx_graph.hip ----
 int lzx_graph_release(lzx_ctx *c);
-int lzx_graph_prepare(lzx_ctx *c);   // builds this rank's share from d_row_ptr/d_col_idx
+int lzx_graph_prepare(lzx_ctx *c);   // builds this rank's share from d_row_ptr/d_col_idx (sharded hand-over: from c->shard)
 
 // ---- lzx_pb.hip ----
 // Builds the propagation-blocked structure for this rank's non-hub entries. d_nh_off: exclusive prefix of the

@@ -93,6 +93,34 @@ eng.set_graph_csr(rp, ci)      # and a second graph on the SAME wired handle
 assert np.allclose(eng.spmv(x), y_ref, rtol=1e-13, atol=0)
 eng.close()
 dist.barrier()
+# the sharded hand-over across processes (option sharded_ingest): every rank sweeps the seeded generator and keeps its OWN rows
+# only; the sparse second chunk's send lists come from those rows through the matrix's symmetry and are checked pairwise by
+# the transport at the hand-over (a disagreement is LZX_ERR_STATE on every rank).  Same bits as the whole-graph hand-over.
+rp3, ci3 = O.gen_rmat(18, 200000, 3000000, 5)
+x3 = np.random.default_rng(11).random(len(rp3) - 1)
+y3 = O.spmv(rp3, ci3, x3)
+got = {}
+for sharded in (0, 3):
+    eng = pkg.Engine(device, propagation_blocking=1, hub_entries=1024, sharded_ingest=sharded)
+    wire(eng)
+    eng.gen_rmat(18, 200000, 3000000, 5)
+    gi = eng.info()
+    assert gi["nnz"] == len(ci3) and gi["exchange_chunk0"] > 0 and gi["exchange_recv"] < (world - 1) * gi["exchange_slice"], gi
+    y = eng.spmv(x3)
+    assert np.allclose(y, y3, rtol=1e-12, atol=0)
+    a, b, _, _, _ = eng.lanczos(np.ones(len(rp3) - 1), 8, want_q=False)
+    got[sharded] = (gi["nnz_local"], gi["exchange_recv"], y, a, b)
+    if sharded:
+        try:
+            eng.get_graph_csr()
+            raise AssertionError("a sharded rank handed out a whole graph")
+        except pkg.LzxError:
+            pass
+    eng.close()
+    dist.barrier()
+assert got[0][0] == got[3][0] and got[0][1] == got[3][1] and all(np.array_equal(p, q) for p, q in zip(got[0][2:], got[3][2:]))
+if rank == 0:
+    print(f"[ipc_ranks] world={world}: sharded hand-over == whole-graph hand-over bit for bit (nnz_local {got[3][0]}, receives {got[3][1]} doubles)", flush=True)
 # a peer that never arrives is an error after the deadline, not a hang: rank 0 enters a collective alone
 import time
 os.environ["LZX_IPC_TIMEOUT_MS"] = "400"
