@@ -283,7 +283,7 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           graph), the matrix must be symmetric as documented above (the sparse exchange lists rely on it),
  *                           and "reference_order" stays a one-rank instrument.  Not available for lzx_set_graph_csr (the caller
  *                           already holds that graph whole).  Default 0.  C5, rank 0 of 8: 19 GB at the peak and 8.7 GB
- *                           resident instead of 102 / 17+ GB, 14.7 s instead of 5.8 s (profiles/r4_sharded_ingest.txt).
+ *                           resident instead of 102 / 17+ GB, 12.7 s instead of 5.8 s (profiles/r4_sharded_ingest.txt).
  * These twelve are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
  * "phase_mask", "exchange_at_world_1", ...) exist only in liblzx_dbg.so, the same sources built with -DLZX_DEBUG_KNOBS
  * (`make debug`); tools/perf_probe.py and the tests that need them load that library.                               */

@@ -459,6 +459,30 @@ k_shard_emit(lzx_ctx::lzx_key_source s, ShardFilter f, u64 *out, unsigned long l
     if (!out && lane == 0 && mine) atomicAdd(count, mine);
 }
 
+// Sweeps 1 and 2: how many keys each of the `mod` classes will hold, all classes in ONE pass over the source (a count pass
+// per class would re-draw the source as often again as the fill passes do).  Block-private histogram in LDS.
+__global__ void __launch_bounds__(256)
+k_shard_class_counts(lzx_ctx::lzx_key_source s, ShardFilter f, unsigned long long *counts)
+{
+    extern __shared__ u32 hist[];
+    for (u32 j = threadIdx.x; j < f.mod; j += blockDim.x) hist[j] = 0;
+    __syncthreads();
+    const u64 total = s.kind == 2 ? s.m : s.draws;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        u64 u = 0, v = 0;
+        bool ok = true;
+        if (s.kind == 2) { u = s.d_src[e]; v = s.d_dst[e]; }
+        else ok = gen_draw(s.kind, s.scale, s.n, s.seed, s.ta, s.tab, s.tabc, e, u, v);
+        if (!ok) continue;
+        if (f.mode == 0 || f.rank_of_old[v] < f.hub) atomicAdd(&hist[u % f.mod], 1u);
+        if (u != v && (f.mode == 0 || f.rank_of_old[u] < f.hub)) atomicAdd(&hist[v % f.mod], 1u);
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < f.mod; j += blockDim.x)
+        if (hist[j]) atomicAdd(&counts[j], (unsigned long long)hist[j]);
+}
+
 // sorted unique keys: every row is one run; its length goes to out[row] (two atomics per row, none contended)
 __global__ void k_shard_run_lengths(const u64 *keys, u64 cnt, u32 *out)
 {
@@ -593,22 +617,26 @@ static int sorted_unique_keys(lzx_ctx *c, u64 *d_keys, u64 nkeys, u64 **d_uniq_o
 static const u64 LZX_SHARD_BATCH = 1ull << 28;   // directed keys per sweep batch when the option leaves the choice here (2 GiB; about 8 GiB with the sort's buffers)
 
 // One batch of a sweep: the filtered keys of the source, sorted, unique.  *d_uniq is null when the batch is empty.
-static int shard_batch(lzx_ctx *c, const ShardFilter &f, u64 **d_uniq, u64 *cnt)
+// `known` >= 0: the batch's key count is already known (k_shard_class_counts); otherwise a count pass finds it.
+static int shard_batch(lzx_ctx *c, const ShardFilter &f, u64 **d_uniq, u64 *cnt, long long known = -1)
 {
     hipStream_t st = c->stream;
     *d_uniq = nullptr;
     *cnt = 0;
     const u64 total = c->shard.kind == 2 ? c->shard.m : c->shard.draws;
-    if (total == 0) return LZX_OK;
-    unsigned long long *d_cnt = nullptr, h_cnt = 0;
+    if (total == 0 || known == 0) return LZX_OK;
+    unsigned long long *d_cnt = nullptr, h_cnt = known > 0 ? (unsigned long long)known : 0;
     LZX_TRY(dev_alloc(&d_cnt, 1));
     const u32 grid = (u32)std::min<u64>((total + 255) / 256, (u64)c->cu_count * 32);
-    hipError_t e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_shard_emit, dim3(grid), dim3(256), 0, st, c->shard, f, (u64 *)nullptr, d_cnt);
-        e = hipMemcpyAsync(&h_cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipSuccess;
+    if (known < 0) {
+        e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_shard_emit, dim3(grid), dim3(256), 0, st, c->shard, f, (u64 *)nullptr, d_cnt);
+            e = hipMemcpyAsync(&h_cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { dev_free(d_cnt); LZX_FAIL(LZX_ERR_HIP, "sharded hand-over, count pass: %s", hipGetErrorString(e)); }
     if (h_cnt == 0) { dev_free(d_cnt); return LZX_OK; }
     u64 *d_keys = nullptr;
@@ -638,11 +666,28 @@ static int shard_count_sweep(lzx_ctx *c, int mode, const u32 *d_rank_of_old, u32
 {
     LZX_HIP(hipMemsetAsync(d_out, 0, sizeof(u32) * c->n, c->stream));
     const u32 classes = shard_classes(c);
+    const u64 total = c->shard.kind == 2 ? c->shard.m : c->shard.draws;
+    std::vector<unsigned long long> per_class(classes, 0);
+    if (total) {
+        unsigned long long *d_counts = nullptr;
+        LZX_TRY(dev_alloc(&d_counts, classes));
+        ShardFilter f;
+        f.mode = mode; f.mod = classes; f.rank_of_old = d_rank_of_old; f.hub = hub;
+        hipError_t e = hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * classes, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_shard_class_counts, dim3((u32)std::min<u64>((total + 255) / 256, (u64)c->cu_count * 32)), dim3(256),
+                               sizeof(u32) * classes, c->stream, c->shard, f, d_counts);
+            e = hipMemcpyAsync(per_class.data(), d_counts, sizeof(unsigned long long) * classes, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        dev_free(d_counts);
+        if (e != hipSuccess) LZX_FAIL(LZX_ERR_HIP, "sharded hand-over, class counts: %s", hipGetErrorString(e));
+    }
     for (u32 cls = 0; cls < classes; ++cls) {
         ShardFilter f;
         f.mode = mode; f.mod = classes; f.cls = cls; f.rank_of_old = d_rank_of_old; f.hub = hub;
         u64 *d_uniq = nullptr, cnt = 0;
-        LZX_TRY(shard_batch(c, f, &d_uniq, &cnt));
+        LZX_TRY(shard_batch(c, f, &d_uniq, &cnt, (long long)per_class[cls]));
         if (cnt) hipLaunchKernelGGL(k_shard_run_lengths, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, c->stream, d_uniq, cnt, d_out);
         hipError_t e = hipStreamSynchronize(c->stream);
         dev_free(d_uniq);
