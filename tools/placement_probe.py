@@ -15,7 +15,7 @@ WORK = {"c3": (24, 10_000_000, 200_000_000), "er": (0, 10_000_000, 100_000_000),
 scale, n, draws = WORK[work]
 import time
 for i in range(reps):
-    for trials in (0, 7):
+    for trials in [int(a) for a in os.environ.get("PLACEMENT_TRIALS", "0,7").split(",")]:
         e = pkg.Engine(0, placement_trials=trials)
         t = time.time()
         if scale == 0:
