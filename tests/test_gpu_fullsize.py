@@ -344,7 +344,20 @@ def test_c5_size_graph(pkg):
         assert len(ids) == n // 8 and np.array_equal(np.sort(degrees[ids])[::-1], degrees[order[r::8]]), r   # the degree ranks r, r + 8, ...
         assert np.array_equal(v, degrees[ids].astype(np.float64)), (r, int(np.flatnonzero(v != degrees[ids])[0]))
         assert float(v.sum()) == float(e.info()["nnz_local"])
-    del degrees, order, v, ids
+    # C5's 8-rank form WITHOUT the whole graph on any rank (option sharded_ingest): rank 5 of another group sweeps the generator in
+    # bounded batches and keeps its own rows -- the same rows, the same tables, every row sum equal to the whole-graph rank 5's
+    g5 = grp.engines[5].info()
+    grp_s = pkg.LocalGroup([0] * 8, sharded_ingest=1)
+    es = grp_s.engines[5]
+    es.gen_rmat(scale, n, draws, 1234)
+    gs = es.info()
+    assert all(gs[k] == g5[k] for k in g5), {k: (gs[k], g5[k]) for k in g5 if gs[k] != g5[k]}
+    v_s, ids_s = es.rank_row_sums()
+    assert np.array_equal(ids_s, ids) and np.array_equal(v_s, v)
+    with pytest.raises(pkg.LzxError):
+        es.get_graph_csr()                                    # nobody holds the graph
+    grp_s.close()
+    del degrees, order, v, ids, v_s, ids_s
     grp.close()
 
     eng = pkg.Engine(0)
