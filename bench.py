@@ -7,9 +7,8 @@ A "step" is one Lanczos iteration (serial/lib/lanczos.cc:21-53) on a graph alrea
 HBM.  The decomposition that is timed is BASELINE's: k = the workload's Krylov dimension (50; C5 30; C1 20 -- what
 parallel-final/main.cu:104-116 times), prepared with lzx_lanczos_prepare_f64(x0, k); the timed region is exactly K = --steps
 iterations of it (lzx_lanczos_run_steps), bracketed by a barrier and a device synchronisation on both sides, MAX over
-ranks; the W warm-up iterations are iterations 0 .. W - 1 of the same decomposition where W + K <= k (otherwise a short
-decomposition of their own in front of it), and whatever is left of the k iterations completes the decomposition outside
-the clock (config.k and steps are reported separately; --steps above the workload's k lengthens the decomposition to K).  N > 1: one process per GPU (torch.distributed.run), rows
+ranks; the remaining k - K iterations then complete the decomposition outside the clock (config.k and steps are reported
+separately; --steps above the workload's k lengthens the decomposition to K).  N > 1: one process per GPU (torch.distributed.run), rows
 dealt to ranks by degree rank, the new Lanczos vector re-assembled each iteration by an RCCL all-gather
 inside liblzx.so (torch.distributed only carries the 128-byte communicator id, the barrier and the max).
 The same graph is used at every N, so scaling is "strong".
@@ -256,34 +255,23 @@ def main():
         """W untimed iterations (a decomposition of their own), then the workload's k-step decomposition is prepared and
         exactly K of its iterations run between barrier + synchronise on both sides, max over ranks; the other k - K follow
         outside the clock."""
-        # Where they fit, the W warm-up iterations are the FIRST W of the same k-step decomposition (an iteration costs the same
-        # at every j), so the clock starts on a GPU that is multiplying -- not behind the 80 MB upload of x0 and the basis
-        # set-up that would otherwise sit between a separate warm-up decomposition and the timed one.
-        same = 0 < W and W + K <= k_cfg
-        if W > 0 and not same:
+        if W > 0:
             e.lanczos_prepare(x0, W)
             e.lanczos_run()
         t_in = time.perf_counter()
         e.lanczos_prepare(x0, k_cfg)     # x0 uploaded, q_0 in HBM, basis sized for k columns: inputs resident before the clock starts
         barrier(e)
         t_in = time.perf_counter() - t_in
-        t_rest = 0.0
-        if same:
-            t_rest = time.perf_counter()
-            e.lanczos_run_steps(W)       # untimed: iterations 0 .. W - 1
-            barrier(e)
-            t_rest = time.perf_counter() - t_rest
         t0 = time.perf_counter()
         st = e.lanczos_run_steps(K)      # exactly K iterations; returns after a stream synchronise
         barrier(e)
         elapsed = time.perf_counter() - t0
         assert st["iters"] == K, st
-        done = K + (W if same else 0)
-        t1 = time.perf_counter()
-        if k_cfg > done:
-            e.lanczos_run_steps(k_cfg - done)
+        t_rest = time.perf_counter()
+        if k_cfg > K:
+            e.lanczos_run_steps(k_cfg - K)
         barrier(e)
-        t_rest += time.perf_counter() - t1
+        t_rest = time.perf_counter() - t_rest
         m = {}
         if dist is not None:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
