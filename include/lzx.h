@@ -123,8 +123,8 @@ int lzx_comm_ipc_init(lzx_handle h, const uint8_t *blobs /* [world][LZX_IPC_BLOB
  * lzx_set_graph_csr: upload of IA/JA, parallel-final/lib/cu_lanczos.cu:88-94 (`row_offset[n+1]`,
  * `col_idx[2E]`).  row_ptr is 64-bit as in serial/ (serial/lib/adjMatrix.h:23-24);
  * lzx_set_graph_csr32 takes parallel-final's `unsigned` arrays as they are.  Every rank of a
- * communicator passes the same whole graph and keeps its share (lzx_gen_graph / lzx_set_graph_edges with
- * option "sharded_ingest": never the whole graph on any device).                                 */
+ * communicator passes the same whole graph and keeps its share (with option "sharded_ingest" the graph
+ * never sits whole on any device: the CSR is streamed from the caller's memory).                  */
 int lzx_set_graph_csr(lzx_handle h, uint64_t n, uint64_t nnz, const uint64_t *row_ptr,
                       const uint32_t *col_idx);
 int lzx_set_graph_csr32(lzx_handle h, uint32_t n, uint32_t nnz, const uint32_t *row_ptr,
@@ -271,7 +271,7 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           that one buffer decides up to 15 % of the SpMV on uniform graphs and 1-2 % on R-MAT ones for the
  *                           life of the allocation -- the reference's cudaMalloc blocks (cu_lanczos.cu:37-86) have no
  *                           counterpart.  Default 7 (fewer when the stream is several GB); 0 = take the first allocation.
- *   "sharded_ingest"        s > 0: lzx_gen_graph and lzx_set_graph_edges build the graph WITHOUT ever holding all of it on one
+ *   "sharded_ingest"        s > 0: every hand-over entry point builds the graph WITHOUT ever holding all of it on one
  *                           device -- the loader of parallel-final/lib/adjMatrix.cc:21-46 for graphs beyond one card (SURVEY.md 7.1
  *                           step 7).  The whole-graph hand-over sorts all 2 m directed entries at once and leaves the whole CSR
  *                           on every rank; with this option a rank sweeps the source (the seeded generator re-drawn, or the
@@ -281,8 +281,10 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           (same bits in every result).  s = 1: batches of 2^28 entries; s >= 2: exactly s batches per sweep
  *                           (tests).  With several ranks lzx_get_graph_csr then fails with LZX_ERR_STATE (no rank holds the
  *                           graph), the matrix must be symmetric as documented above (the sparse exchange lists rely on it),
- *                           and "reference_order" stays a one-rank instrument.  Not available for lzx_set_graph_csr (the caller
- *                           already holds that graph whole).  Default 0.  C5, rank 0 of 8: 19 GB at the peak and 8.7 GB
+ *                           and "reference_order" stays a one-rank instrument.  lzx_set_graph_csr / _csr32: the CSR stays in the
+ *                           caller's memory and is streamed past the device in chunks of whole rows (row_ptr once, col_idx
+ *                           twice); the rank keeps its own rows -- what parallel-two-cards does for its two halves
+ *                           (parallel-two-cards/lib/cu_lanczos.cu:94-95,108-109).  Default 0.  C5, rank 0 of 8: 19 GB at the peak and 8.7 GB
  *                           resident instead of 102 / 17+ GB, 12.7 s instead of 5.8 s (profiles/r4_sharded_ingest.txt).
  * These twelve are all liblzx.so knows.  The experiment knobs and test hooks behind DESIGN.md's tuning log ("pb_*",
  * "phase_mask", "exchange_at_world_1", ...) exist only in liblzx_dbg.so, the same sources built with -DLZX_DEBUG_KNOBS

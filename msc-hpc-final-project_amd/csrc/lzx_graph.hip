@@ -654,6 +654,88 @@ static int shard_batch(lzx_ctx *c, const ShardFilter &f, u64 **d_uniq, u64 *cnt,
     return sorted_unique_keys(c, d_keys, h_cnt, d_uniq, cnt);
 }
 
+// ---- kind 3: the caller's CSR stays in host memory and passes through the device in chunks of whole rows -----------------
+// one wavefront per row of the chunk (rows strided over the grid); cols = the chunk's entries, row_ptr = device copy of ALL offsets.
+// mode 1: out[row] = entries whose column is staged (rank < hub);  mode 2: this rank's rows are copied to col_out[own_ptr[row] ..]
+__global__ void __launch_bounds__(64)
+k_shard_csr_chunk(int mode, const u64 *row_ptr, u64 r0, u64 r1, const u32 *cols, u64 n, const u32 *rank_of_old, u32 hub, u32 *out,
+                  const u32 *gidx_of_old, u32 n_loc_pad, u32 me, const u64 *own_ptr, u32 *col_out, u32 *bad)
+{
+    const u32 lane = threadIdx.x;
+    const u64 base = row_ptr[r0];
+    for (u64 r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
+        const u64 beg = row_ptr[r] - base, end = row_ptr[r + 1] - base;
+        if (mode == 1) {
+            u32 cnt = 0;
+            for (u64 k = beg + lane; k < end; k += 64) {
+                const u32 cl = cols[k];
+                if (cl >= n) { bad[0] = 1u; continue; }
+                cnt += rank_of_old[cl] < hub ? 1u : 0u;
+            }
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if (lane == 0) out[r] = cnt;
+        } else if (gidx_of_old[r] / n_loc_pad == me) {
+            const u64 dst = own_ptr[r];
+            for (u64 k = beg + lane; k < end; k += 64) {
+                const u32 cl = cols[k];
+                if (cl >= n) bad[0] = 1u;
+                col_out[dst + (k - beg)] = cl < n ? cl : 0u;
+            }
+        }
+    }
+}
+
+// Streams the host CSR through the device: rows in chunks of at most LZX_SHARD_BATCH / 2 entries (or shard_opt chunks).
+static int shard_csr_sweep(lzx_ctx *c, int mode, const u32 *d_rank_of_old, u32 hub, u32 *d_out)
+{
+    hipStream_t st = c->stream;
+    const u64 n = c->n;
+    const u64 *rp = c->shard.h_row_ptr;
+    const u64 nnz = rp[n];
+    if (mode == 1) LZX_HIP(hipMemsetAsync(d_out, 0, sizeof(u32) * n, st));
+    if (nnz == 0) return LZX_OK;
+    u64 cap = c->shard_opt >= 2 ? (nnz + (u64)c->shard_opt - 1) / (u64)c->shard_opt : LZX_SHARD_BATCH / 2;
+    u64 widest = 0;
+    for (u64 r = 0; r < n; ++r) widest = std::max(widest, rp[r + 1] - rp[r]);
+    cap = std::max(cap, widest);   // a chunk holds whole rows
+    u64 *d_rp = nullptr;
+    u32 *d_cols = nullptr, *d_bad = nullptr, bad = 0;
+    LZX_TRY(dev_alloc(&d_rp, n + 1));
+    int rc = dev_alloc(&d_cols, cap);
+    if (rc == LZX_OK) rc = dev_alloc(&d_bad, 1);
+    hipError_t e = hipSuccess;
+    if (rc == LZX_OK) {
+        e = hipMemcpyAsync(d_rp, rp, sizeof(u64) * (n + 1), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(u32), st);
+        for (u64 r0 = 0; e == hipSuccess && r0 < n;) {
+            u64 r1 = r0 + 1;
+            // the last row r1 with rp[r1] - rp[r0] <= cap (binary search on the host's offsets)
+            u64 lo = r0 + 1, hi = n;
+            while (lo < hi) {
+                const u64 mid = (lo + hi + 1) >> 1;
+                if (rp[mid] - rp[r0] <= cap) lo = mid; else hi = mid - 1;
+            }
+            r1 = lo;
+            const u64 cnt = rp[r1] - rp[r0];
+            if (cnt) {
+                e = hipMemcpyAsync(d_cols, c->shard.h_col_idx + rp[r0], sizeof(u32) * cnt, hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(k_shard_csr_chunk, dim3((u32)std::min<u64>(r1 - r0, 1u << 20)), dim3(64), 0, st, mode, d_rp, r0, r1, d_cols, n,
+                                   d_rank_of_old, hub, d_out, c->d_gidx_of_old, c->n_loc_pad, (u32)c->rank, c->d_row_ptr, c->d_col_idx, d_bad);
+                e = hipStreamSynchronize(st);   // d_cols is reused by the next chunk
+            }
+            r0 = r1;
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(u32), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    dev_free(d_rp); dev_free(d_cols); dev_free(d_bad);
+    if (rc != LZX_OK) return rc;
+    if (e != hipSuccess) LZX_FAIL(LZX_ERR_HIP, "sharded hand-over of a host CSR: %s", hipGetErrorString(e));
+    if (bad) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: a column index is >= n");
+    return LZX_OK;
+}
+
 static u32 shard_classes(const lzx_ctx *c)
 {
     if (c->shard_opt >= 2) return (u32)std::min<int64_t>(c->shard_opt, 4096);
@@ -664,6 +746,7 @@ static u32 shard_classes(const lzx_ctx *c)
 // Sweeps 1 and 2: d_out[v] (zeroed here) = number of distinct entries of row v (mode 0), or of those whose column is staged (mode 1).
 static int shard_count_sweep(lzx_ctx *c, int mode, const u32 *d_rank_of_old, u32 hub, u32 *d_out)
 {
+    if (c->shard.kind == 3) return shard_csr_sweep(c, 1, d_rank_of_old, hub, d_out);   // (mode 0 -- degrees -- comes from row_ptr itself)
     LZX_HIP(hipMemsetAsync(d_out, 0, sizeof(u32) * c->n, c->stream));
     const u32 classes = shard_classes(c);
     const u64 total = c->shard.kind == 2 ? c->shard.m : c->shard.draws;
@@ -719,6 +802,7 @@ static int shard_build_rows(lzx_ctx *c)
     if (own >= (1ull << 32)) LZX_FAIL(LZX_ERR_LIMIT, "%llu entries in this rank's rows: use more ranks (limit 2^32 per rank)", (unsigned long long)own);
     LZX_TRY(dev_alloc(&c->d_col_idx, own));
     if (own == 0) return LZX_OK;
+    if (c->shard.kind == 3) return shard_csr_sweep(c, 2, nullptr, 0, nullptr);
     // vertex ranges holding about equal shares of the rank's entries
     u32 blocks = c->shard_opt >= 2 ? (u32)std::min<int64_t>(c->shard_opt, 4096) : (u32)std::max<u64>(1, (own + LZX_SHARD_BATCH / 2 - 1) / (LZX_SHARD_BATCH / 2));
     std::vector<u64> target(blocks + 1), bound(blocks + 1), at(blocks + 1);
@@ -1339,7 +1423,21 @@ static int shard_handover(lzx_ctx *c, const lzx_ctx::lzx_key_source &src)
     c->n = src.n;
     c->shard = src;
     int rc = dev_alloc(&c->d_shard_deg, src.n);
-    if (rc == LZX_OK) rc = shard_count_sweep(c, 0, nullptr, 0, c->d_shard_deg);
+    if (rc == LZX_OK && src.kind == 3) {   // a CSR carries its degrees: row_ptr alone crosses for them
+        u64 *d_rp = nullptr;
+        u32 *d_ids = nullptr;
+        rc = dev_alloc(&d_rp, src.n + 1);
+        if (rc == LZX_OK) rc = dev_alloc(&d_ids, src.n);
+        if (rc == LZX_OK) {
+            hipError_t e = hipMemcpyAsync(d_rp, src.h_row_ptr, sizeof(u64) * (src.n + 1), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_degrees, dim3((u32)((src.n + 255) / 256)), dim3(256), 0, c->stream, d_rp, c->d_shard_deg, d_ids, src.n);
+                e = hipStreamSynchronize(c->stream);
+            }
+            if (e != hipSuccess) { lzx_set_error("sharded hand-over: %s", hipGetErrorString(e)); rc = LZX_ERR_HIP; }
+        }
+        dev_free(d_rp); dev_free(d_ids);
+    } else if (rc == LZX_OK) rc = shard_count_sweep(c, 0, nullptr, 0, c->d_shard_deg);
     if (rc == LZX_OK) {
         unsigned long long *d_tot = nullptr, tot = 0;
         rc = dev_alloc(&d_tot, 1);
@@ -1462,6 +1560,11 @@ static int set_csr_common(lzx_ctx *c, u64 n, u64 nnz, const u64 *row_ptr64, cons
     if (n > 0xffffffffull) LZX_FAIL(LZX_ERR_LIMIT, "lzx_set_graph_csr: more than 2^32 vertices");
     for (u64 i = 0; i < n; ++i)
         if (row_ptr64[i] > row_ptr64[i + 1]) LZX_FAIL(LZX_ERR_ARG, "lzx_set_graph_csr: row_ptr decreases at row %llu", (unsigned long long)i);
+    if (c->shard_opt > 0) {   // sharded hand-over: the CSR stays with the caller and is streamed; this rank keeps its own rows
+        lzx_ctx::lzx_key_source ks;
+        ks.kind = 3; ks.n = n; ks.h_row_ptr = row_ptr64; ks.h_col_idx = col_idx;
+        return shard_handover(c, ks);
+    }
     lzx_graph_release(c);
     c->n = n;
     c->nnz = nnz;

@@ -127,11 +127,14 @@ struct lzx_ctx {
     // -- a seeded generator or an edge list resident on the device -- and every vertex's degree, counted in bounded sweeps
     // before lzx_graph_prepare starts.  Both live only for the duration of the entry point.
     struct lzx_key_source {
-        int kind = -1;                 // -1: none (whole-graph hand-over); 0 Erdos-Renyi, 1 R-MAT (lzx_gen_graph); 2 edge list
+        int kind = -1;                 // -1: none (whole-graph hand-over); 0 Erdos-Renyi, 1 R-MAT (lzx_gen_graph); 2 edge list;
+                                       // 3: the caller's CSR in HOST memory, streamed through the device in row chunks
         u32 scale = 0, ta = 0, tab = 0, tabc = 0;
         u64 n = 0, draws = 0, seed = 0;
         const u32 *d_src = nullptr, *d_dst = nullptr;   // kind 2: m endpoint pairs
         u64 m = 0;
+        const u64 *h_row_ptr = nullptr;                 // kind 3: row_ptr[n + 1], col_idx[row_ptr[n]] (host, valid during the call)
+        const u32 *h_col_idx = nullptr;
     } shard;
     u32 *d_shard_deg = nullptr;        // [n] degree of every vertex, caller's order
     bool sharded = false;              // the graph on this handle came through the sharded hand-over

@@ -81,6 +81,10 @@ std::shared_ptr<deviceGraph> adjMatrix::device_graph() const {
   const auto t0 = std::chrono::steady_clock::now();
   auto g = make_handles();
   // stored entries: row_offset[n] (2 * edge_count is one too many per self loop of the file)
+  // several cards: every card receives ITS OWN rows only, as parallel-two-cards gives each of its two cards its half of IA / JA
+  // (parallel-two-cards/lib/cu_lanczos.cu:94-95,108-109) -- the CSR stays here and is streamed past each card in chunks
+  if (g->ranks.size() > 1 && !env_on("LZX_WHOLE_GRAPH_PER_CARD"))
+    for (lzx_ctx *h : g->ranks) lzx_or_throw(lzx_set_option(h, "sharded_ingest", 1), "lzx_set_option(sharded_ingest)");
   for (lzx_ctx *h : g->ranks) lzx_or_throw(lzx_set_graph_csr32(h, n, row_offset[n], row_offset, col_idx), "lzx_set_graph_csr32");
   g->setup_ms = seconds_since(t0) * 1e3;
   dev = g;

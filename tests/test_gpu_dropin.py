@@ -102,6 +102,21 @@ def test_cpp_classes_several_gpu_handles_and_device_ingest(pkg, tmp_path, monkey
                 assert rc == n, H.host_last_error()
                 assert used[0] == len(devices)
                 assert np.abs(ans - g["ans"]).max() <= 1e-10 * np.abs(g["ans"]).max(), (devices, device_multout)
+        # the CSR built on the HOST (std::sort path of the loader), handed to three cards: each card receives its own rows only
+        # (lzx_set_graph_csr32 with option sharded_ingest, as parallel-two-cards gives each card its half of IA / JA) -- the same
+        # bits as with the whole CSR on every card
+        got = {}
+        for whole in ("0", "1"):
+            with monkeypatch.context() as mp:
+                mp.setenv("LZX_HOST_INGEST", "1")
+                mp.setenv("LZX_WHOLE_GRAPH_PER_CARD", whole)
+                ans, used = np.zeros(n), np.zeros(1, dtype=np.uint32)
+                dv = (ctypes.c_int * 3)(0, 0, 0)
+                rc = H.host_expm_path_devices(mtx.encode(), k, dv, 3, 1, ans.ctypes.data_as(_f64p), n, None, None, used.ctypes.data_as(_u32p))
+                assert rc == n and used[0] == 3, H.host_last_error()
+                assert np.abs(ans - g["ans"]).max() <= 1e-10 * np.abs(g["ans"]).max(), whole
+                got[whole] = ans
+        assert np.array_equal(got["0"], got["1"])
 
 
 def test_final_cli(tmp_path):

@@ -18,6 +18,13 @@ def _build(pkg, world, how, spec, **options):
         g.gen_rmat(*spec)
     elif how == "er":
         g.gen_er(*spec)
+    elif how == "csr":
+        g.set_graph_csr(*spec)
+    elif how == "csr32":
+        engines = g.engines if world > 1 else [g]
+        for e in engines:
+            e.set_graph_csr32(spec[0].astype(np.uint32), spec[1])
+        g.n = len(spec[0]) - 1
     else:
         g.set_graph_edges(*spec)
     return g
@@ -38,7 +45,9 @@ def test_sharded_equals_whole_graph_bit_for_bit(pkg, oracle, world):
     src = (rng.random(m) ** 2 * n).astype(np.uint32)
     dst = (rng.random(m) ** 2 * n).astype(np.uint32)
     src[:50] = dst[:50]
-    cases = (("rmat", (16, n, 400000, 21)), ("er", (n, 250000, 22)), ("edges", (n, src, dst)))
+    # ... and a CSR the caller holds in host memory (streamed past the device in row chunks; 64- and 32-bit offsets)
+    rp_h, ci_h = O.gen_rmat(16, n, 400000, 23)
+    cases = (("rmat", (16, n, 400000, 21)), ("er", (n, 250000, 22)), ("edges", (n, src, dst)), ("csr", (rp_h, ci_h)), ("csr32", (rp_h, ci_h)))
     # plain; blocked with the default second chunk; blocked with every run reduced and small gather items
     modes = (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=512),
              dict(propagation_blocking=1, hub_entries=256, pb_reduce=16, pb_target=2048))
@@ -94,6 +103,20 @@ def test_sharded_rank_holds_its_own_rows_only(pkg, oracle):
     rp1, ci1 = one.get_graph_csr()
     assert np.array_equal(rp1, rp) and np.array_equal(ci1, ci)
     one.close()
+
+
+def test_sharded_csr_rejects_a_bad_column(pkg, oracle):
+    rp, ci = oracle.gen_er(5000, 30000, 9)
+    bad = ci.copy()
+    bad[len(bad) // 2] = 5000
+    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=256)):
+        eng = pkg.Engine(0, sharded_ingest=3, **mode)
+        with pytest.raises(pkg.LzxError):
+            eng.set_graph_csr(rp, bad)
+        eng.set_graph_csr(rp, ci)                                # the handle is still good
+        x = np.random.default_rng(1).random(5000)
+        assert np.allclose(eng.spmv(x), oracle.spmv(rp, ci, x), rtol=1e-13, atol=0)
+        eng.close()
 
 
 def test_sharded_edge_list_errors_and_empty(pkg):
