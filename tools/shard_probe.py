@@ -53,6 +53,14 @@ class Peak:
         self.t.join()
 
 
+HOST_CSR = None
+if os.environ.get("SHARD_PROBE_SOURCE") == "csr":   # the same graph as a CSR in host memory (lzx_set_graph_csr), streamed when sharded
+    helper = pkg.Engine(0)
+    (helper.gen_er(n, draws, seed) if kind == 0 else helper.gen_rmat(scale, n, draws, seed))
+    HOST_CSR = helper.get_graph_csr()
+    helper.close()
+
+
 def build(rank, **options):
     if world == 1:
         engines = [pkg.Engine(0, **options)]
@@ -63,7 +71,9 @@ def build(rank, **options):
     base = mem_used()
     t = time.perf_counter()
     with Peak() as pk:
-        if kind == 0:
+        if HOST_CSR is not None:
+            e.set_graph_csr(*HOST_CSR)
+        elif kind == 0:
             e.gen_er(n, draws, seed)
         else:
             e.gen_rmat(scale, n, draws, seed)
@@ -84,7 +94,7 @@ for rank in ranks:
         else:
             sums = e.spmv(np.ones(n))
         res[tag] = sums
-        print(f"{work} rank {rank} of {world} [{tag}]: hand-over {dt:.2f} s, peak {peak / 1e9:.2f} GB above the idle handle, "
+        print(f"{work}{' (host CSR)' if HOST_CSR is not None else ''} rank {rank} of {world} [{tag}]: hand-over {dt:.2f} s, peak {peak / 1e9:.2f} GB above the idle handle, "
               f"resident afterwards {resident / 1e9:.2f} GB; nnz={gi['nnz']} nnz_local={gi['nnz_local']} pb_values={gi['pb_values']}", flush=True)
         for x in engines:
             x.close()
