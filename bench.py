@@ -44,8 +44,9 @@ WORKLOADS = {
     "er": ("ER: Erdos-Renyi G(n, M) n=10,000,000, 100M draws (north_star's 100 M-edge graph), seed 1234", "er", 0,
            10_000_000, 100_000_000, 1234, 50),
     "er1m": ("ER: Erdos-Renyi n=1,000,000, 10M draws, seed 1234", "er", 0, 1_000_000, 10_000_000, 1234, 50),
-    # 3.9e9 stored entries (> 2^32): every rank generates and keeps the whole graph (17 GB) and reshapes its own rows; fits
-    # one MI355X too (about 100 iter/s there).  Use --no-cpu-baseline at N = 1: the host loop takes minutes per iteration.
+    # 3.9e9 stored entries (> 2^32).  At N > 1 every rank sweeps the generator in bounded batches and keeps its own rows only
+    # (option sharded_ingest: 19 GB at the peak for a rank of 8 instead of 102 GB); the whole graph also fits one MI355X (about
+    # 110 iter/s there).  Use --no-cpu-baseline at N = 1: the host loop takes minutes per iteration.
     "c5": ("C5: R-MAT scale 27 (a,b,c,d)=(.57,.19,.19,.05), endpoints >= n re-drawn, n=100,000,000, 2G draws, "
            "seed 1234", "rmat", 27, 100_000_000, 2_000_000_000, 1234, 30),
 }
