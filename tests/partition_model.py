@@ -80,3 +80,59 @@ def nnz_per_rank(row_ptr: np.ndarray, world: int) -> np.ndarray:
     deg = np.diff(np.asarray(row_ptr).astype(np.int64))
     order = degree_order(row_ptr)
     return np.array([deg[order[p::world]].sum() for p in range(world)])
+
+
+def _chunk1_codes(row_ptr, world, xs, xs0):
+    """code1[o] = position of vertex o inside chunk 1 of the two-chunk exchange layout (owner * L1 + l), or -1 when the vertex
+    lies in chunk 0 / has no edge (lzx_graph.hip: k_rank_maps)."""
+    n = len(row_ptr) - 1
+    order = degree_order(row_ptr)
+    deg = np.diff(np.asarray(row_ptr).astype(np.int64))
+    r = np.arange(n, dtype=np.int64)
+    p, l = r % world, r // world
+    L1 = xs - xs0
+    code_of_rank = np.where((l >= xs0) & (deg[order] > 0), p * L1 + (l - xs0), -1)
+    code1 = np.empty(n, dtype=np.int64)
+    code1[order] = code_of_rank
+    owner = np.empty(n, dtype=np.int64)
+    owner[order] = p
+    return code1, owner, L1
+
+
+def sparse_lists_whole(row_ptr, col_idx, world, rank, xs, xs0):
+    """The sparse second chunk's two sides derived from the WHOLE graph (lzx_graph.hip: k_sx_mark):
+    ref[r * L1 + l]  : a row of `rank` has an entry in the column that is chunk-1 entry l of rank r   (what it receives)
+    want[p * L1 + l] : a row of rank p has an entry in the column that is chunk-1 entry l of `rank`   (what it sends to p)"""
+    code1, owner, L1 = _chunk1_codes(row_ptr, world, xs, xs0)
+    n = len(row_ptr) - 1
+    deg = np.diff(np.asarray(row_ptr).astype(np.int64))
+    row_of_entry = np.repeat(np.arange(n, dtype=np.int64), deg)
+    cc = code1[np.asarray(col_idx).astype(np.int64)]
+    ok = cc >= 0
+    ref = np.zeros(world * L1, dtype=bool)
+    want = np.zeros(world * L1, dtype=bool)
+    mine = ok & (owner[row_of_entry] == rank)
+    ref[cc[mine]] = True
+    to_me = ok & (cc // max(L1, 1) == rank)
+    want[owner[row_of_entry[to_me]] * L1 + cc[to_me] % max(L1, 1)] = True
+    return ref, want
+
+
+def sparse_lists_own(row_ptr, col_idx, world, rank, xs, xs0):
+    """The same two sides from the rank's OWN rows alone (sharded hand-over, lzx_graph.hip: k_sx_mark_own): `ref` as above; `want`
+    through the symmetry of the matrix -- a row of rank p has an entry in my column v exactly when my row v has an entry in a
+    column that rank p owns."""
+    code1, owner, L1 = _chunk1_codes(row_ptr, world, xs, xs0)
+    n = len(row_ptr) - 1
+    deg = np.diff(np.asarray(row_ptr).astype(np.int64))
+    row_of_entry = np.repeat(np.arange(n, dtype=np.int64), deg)
+    cols = np.asarray(col_idx).astype(np.int64)
+    own = owner[row_of_entry] == rank            # the only entries this rank holds
+    ref = np.zeros(world * L1, dtype=bool)
+    want = np.zeros(world * L1, dtype=bool)
+    cc = code1[cols[own]]
+    ref[cc[cc >= 0]] = True
+    my_code = code1[row_of_entry[own]]           # the row's own place in chunk 1 (its owner is `rank`)
+    in1 = my_code >= 0
+    want[owner[cols[own][in1]] * L1 + my_code[in1] % max(L1, 1)] = True
+    return ref, want

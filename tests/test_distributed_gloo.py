@@ -118,3 +118,46 @@ def test_partition_rules(pkg):
     rp, _ = O.gen_rmat(14, 12000, 200000, 7)
     per = P.nnz_per_rank(rp, 8)
     assert per.max() <= 1.05 * per.mean()
+
+
+def test_sparse_exchange_lists_from_own_rows(oracle):
+    """The sharded hand-over (option sharded_ingest) never sees other ranks' rows, so it derives what it must SEND to each peer
+    from its own rows through the matrix's symmetry (lzx_graph.hip: k_sx_mark_own).  Stated in numpy beside the whole-graph rule
+    (k_sx_mark): identical on every rank of a symmetric graph -- and every pair of ranks agrees on what travels between them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lzx_partition", os.path.join(os.path.dirname(os.path.abspath(__file__)), "partition_model.py"))
+    P = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(P)
+    O = oracle
+    for (rp, ci), world in ((O.gen_rmat(14, 12000, 200000, 7), 3), (O.gen_er(20000, 60000, 5), 4), (O.gen_rmat(13, 8000, 30000, 2), 8)):
+        xs = P.exchange_len(rp, world)
+        xs0 = max(64, (xs // 8) // 64 * 64)          # a short chunk 0, so that most vertices travel in the sparse chunk
+        assert xs0 < xs
+        L1 = xs - xs0
+        lists = []
+        for rank in range(world):
+            ref_w, want_w = P.sparse_lists_whole(rp, ci, world, rank, xs, xs0)
+            ref_o, want_o = P.sparse_lists_own(rp, ci, world, rank, xs, xs0)
+            assert np.array_equal(ref_w, ref_o) and np.array_equal(want_w, want_o), (world, rank)
+            assert want_o.any() and ref_o.any()
+            lists.append((ref_o, want_o))
+        for p in range(world):                       # what p packs for q is what q expects from p (lzx_comm_check_sparse)
+            for q in range(world):
+                assert np.array_equal(lists[p][1][q * L1:(q + 1) * L1], lists[q][0][p * L1:(p + 1) * L1]), (p, q)
+    # the rule NEEDS the symmetry the boundary documents: drop one direction of one edge and the two derivations part
+    rp, ci = O.gen_er(20000, 60000, 5)
+    world, xs = 4, P.exchange_len(rp, 4)
+    xs0 = max(64, (xs // 8) // 64 * 64)
+    deg = np.diff(rp.astype(np.int64))
+    code1, owner, L1 = P._chunk1_codes(rp, world, xs, xs0)
+    rows = np.repeat(np.arange(len(deg)), deg)
+    k = int(np.flatnonzero((code1[ci.astype(np.int64)] >= 0) & (owner[rows] != owner[ci.astype(np.int64)]))[0])
+    rp2 = rp.copy()
+    rp2[rows[k] + 1:] -= 1
+    ci2 = np.delete(ci, k)
+    differs = False
+    for rank in range(world):
+        a = P.sparse_lists_whole(rp2, ci2, world, rank, xs, xs0)
+        b = P.sparse_lists_own(rp2, ci2, world, rank, xs, xs0)
+        differs |= not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
+    assert differs
