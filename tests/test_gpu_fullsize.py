@@ -160,7 +160,26 @@ def test_eight_ranks_in_process_c3(pkg, oracle):
         assert abs(a[0] - len(ci) / n) <= 1e-14 * a[0], ((overlap, sparse), a[0])
         assert np.allclose(a, a_ref, rtol=5e-9, atol=0) and np.allclose(b, b_ref, rtol=5e-9, atol=0), ((overlap, sparse), a, a_ref, b, b_ref)
         check_recurrence(O, rp, ci, a, b, Q, ("local8_c3", overlap, sparse))
+        if (overlap, sparse) == (1, 1):
+            whole = (y.copy(), a.copy(), b.copy(), [g["nnz_local"] for g in infos])
         del Q, y
+        grp.close()
+    # the same eight ranks through the sharded hand-over (option sharded_ingest; two chunks, the second one sparse -- its send
+    # lists now come from each rank's OWN rows): no handle ever holds the graph, yet tables, SpMV and every coefficient are the
+    # whole-graph group's bit for bit -- from the seeded generator, and from the host CSR streamed past the device
+    for source in ("generator", "host csr"):
+        grp = pkg.LocalGroup([0] * 8, sharded_ingest=1)
+        if source == "generator":
+            grp.gen_rmat(24, n, 200_000_000, 1234)
+        else:
+            grp.set_graph_csr(rp, ci)
+        infos_s = [e.info() for e in grp.engines]
+        assert [g["nnz_local"] for g in infos_s] == whole[3] and [g["exchange_recv"] for g in infos_s] == recv[(1, 1)], source
+        with pytest.raises(pkg.LzxError):
+            grp.engines[3].get_graph_csr()
+        assert np.array_equal(grp.spmv(x), whole[0]), source
+        a, b, _, xn, _ = grp.lanczos(np.ones(n), k, want_q=False)
+        assert xn == xn_ref and np.array_equal(a, whole[1]) and np.array_equal(b, whole[2]), source
         grp.close()
     # the sparse second chunk: every rank receives only what its rows reference
     slice_ = infos[0]["exchange_slice"]
