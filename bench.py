@@ -27,6 +27,10 @@ import numpy as np
 
 # multi-process RCCL on this platform needs dmabuf IPC (the host driver has no legacy IPC); must be set before HIP starts
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# peer-window transport (--transport ipc, or the fallback when RCCL cannot build an engine): a rank waits this long for a peer
+# at a synchronisation point before it fails with LZX_ERR_COMM.  Graph hand-overs of different ranks may end many seconds apart
+# (C5: 13-45 s each), so the bench allows more than the library's default 20 s -- a hang still ends, with an error, after 3 min.
+os.environ.setdefault("LZX_IPC_TIMEOUT_MS", "180000")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
