@@ -869,7 +869,10 @@ int lzx_graph_prepare(lzx_ctx *c)
     bool pb = c->pb_opt > 0 || (c->pb_opt < 0 && n >= (512u << 10) && c->nnz / (u64)world >= (8u << 20));
     // hub entries staged in LDS by k_spmv: 8192 (64 KiB, two workgroups per CU) when k_spmv also gathers from
     // memory; 16384 (128 KiB, one per CU) in propagation-blocking mode, where it only ever reads LDS.
-    u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : (pb ? 16384 : 8192);
+    // (round 4, second session: 18 Ki staged values beside 18 Ki column bands on ONE rank from 4 Mi vertices -- 10 M-vertex graph
+    //  SpMV - 1.9 % in two parity-controlled sweeps, profiles/r4_wide_band.txt; the 1 M-vertex graph loses 2.5 % with more staged
+    //  values and keeps 16 Ki of them)
+    u64 hub = (c->hub_opt >= 0) ? (u64)c->hub_opt : (pb ? (world == 1 && !c->force_multi && n >= (4u << 20) ? LZX_PB_CB_WIDE : 16384) : 8192);
     hub = std::min<u64>(hub, n);
     hub = std::min<u64>(hub, 20000);  // 160 KiB LDS per CU
     hub &= ~1ull;

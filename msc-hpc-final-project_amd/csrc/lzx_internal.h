@@ -53,6 +53,7 @@ static constexpr u32 LZX_TAIL = 64;
 // Propagation blocking (csrc/lzx_pb.hip): column band staged in LDS by the scatter phase (doubles),
 // rows per wavefront-private LDS y tile in the gather phase.
 static constexpr u32 LZX_PB_CB = 16384;
+static constexpr u32 LZX_PB_CB_WIDE = 18432;   // test shape pb_column_band: 144 KiB of x per tile (nine 2 Ki-value staging rounds of the 1 024 threads)
 static constexpr u32 LZX_PB_RB = 1024;
 static constexpr u32 LZX_PB_TARGET = 32768;   // upper limit of the values per gather item (one wavefront each)
 static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
@@ -187,7 +188,7 @@ struct lzx_ctx {
     bool force_multi = false;          // test hook: a 1-rank RCCL communicator runs the several-rank code path, collectives included
     int64_t lazy_opt = -1;             // lazy normalisation (lzx_api.hip): -1 = with several ranks and in blocked mode, 0 off, 1 on
     int64_t side_opt = -1;             // staged-columns kernel on a side stream next to the scatter passes: 1 on, else off
-    int64_t pb_cb_opt = -1;            // column band override (8192 or 16384)
+    int64_t pb_cb_opt = -1;            // column band override (8192, 16384 or, on one rank, 18432)
     u32 pb_cb = LZX_PB_CB;             // x values per column band = per LDS tile of the scatter pass
     int64_t pb_taper_opt = -1;         // tapered scatter unit sizes: -1/1 on, 0 off
     int64_t pb_unit_opt = -1;          // entries per scatter unit override

@@ -44,10 +44,13 @@
 
 namespace {
 
-// 64-bit sort key: row band (24 bits) | column band (16) | row in band (10) | column in band (14)
+// 64-bit sort key: row band (23 bits) | column band (16) | row in band (10) | column in band (15: bands of up to 32 Ki columns;
+// the reduced codes keep their bit 15 for the end-of-piece flag)
+constexpr u32 KEY_LCOL_BITS = 15, KEY_LROW_SHIFT = KEY_LCOL_BITS, KEY_CBAND_SHIFT = KEY_LROW_SHIFT + 10, KEY_RBAND_SHIFT = KEY_CBAND_SHIFT + 16;
+constexpr u32 KEY_LCOL_MASK = (1u << KEY_LCOL_BITS) - 1u;
 __device__ __forceinline__ u64 pack_key(u32 rband, u32 cband, u32 lrow, u32 lcol)
 {
-    return ((u64)rband << 40) | ((u64)cband << 24) | ((u64)lrow << 14) | (u64)lcol;
+    return ((u64)rband << KEY_RBAND_SHIFT) | ((u64)cband << KEY_CBAND_SHIFT) | ((u64)lrow << KEY_LROW_SHIFT) | (u64)lcol;
 }
 
 // one wavefront (64-thread block) per local row, rows strided over the grid (a launch holds at most 2^32 work-items):
@@ -92,7 +95,7 @@ __global__ void k_pb_heads(const u64 *keys, u64 count, u32 *head)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    head[i] = (i == 0 || (keys[i] >> 24) != (keys[i - 1] >> 24)) ? 1u : 0u;
+    head[i] = (i == 0 || (keys[i] >> KEY_CBAND_SHIFT) != (keys[i - 1] >> KEY_CBAND_SHIFT)) ? 1u : 0u;
 }
 
 // runstart[r] = first entry of run r (runid = inclusive scan of head, minus 1)
@@ -138,9 +141,9 @@ __global__ void k_pb_place(const u64 *keys, const u32 *runid_incl, const u32 *ru
     if (fmt[r]) return;
     const u32 pos = vpos[r] + ((u32)i - runstart[r]);
     const u64 k = keys[i];
-    prow[pos] = (uint16_t)((k >> 14) & 0x3ffu);
-    plcol[pos] = (uint16_t)(k & 0x3fffu);
-    if ((pos & 3u) == 0) quad_cband[pos >> 2] = (uint16_t)((k >> 24) & 0xffffu);
+    prow[pos] = (uint16_t)((k >> KEY_LROW_SHIFT) & 0x3ffu);
+    plcol[pos] = (uint16_t)(k & KEY_LCOL_MASK);
+    if ((pos & 3u) == 0) quad_cband[pos >> 2] = (uint16_t)((k >> KEY_CBAND_SHIFT) & 0xffffu);
 }
 
 __global__ void k_pb_fill16(uint16_t *a, u64 count, uint16_t v)
@@ -284,13 +287,13 @@ __global__ void k_pbr_place(const u64 *keys, const u32 *runid_incl, const u32 *r
     const u32 off = (u32)i - runstart[r];
     const u32 pos = estart[r] + off;
     const u64 k = keys[i];
-    const u32 lrow = (u32)((k >> 14) & 0x3ffu);
+    const u32 lrow = (u32)((k >> KEY_LROW_SHIFT) & 0x3ffu);
     const bool last = (off & (LZX_PBR_STEP - 1)) == LZX_PBR_STEP - 1 || i + 1 == count || runid_incl[i + 1] - 1 != r ||
-                      (u32)((keys[i + 1] >> 14) & 0x3ffu) != lrow;
-    rcode[pos] = (uint16_t)((k & 0x3fffu) | (last ? 0x8000u : 0u));
+                      (u32)((keys[i + 1] >> KEY_LROW_SHIFT) & 0x3ffu) != lrow;
+    rcode[pos] = (uint16_t)((k & KEY_LCOL_MASK) | (last ? 0x8000u : 0u));
     rrow[pos] = (uint16_t)lrow;
     if ((off & (LZX_PBR_STEP - 1)) == 0) {
-        step_cband[pos / LZX_PBR_STEP] = (uint16_t)((k >> 24) & 0xffffu);
+        step_cband[pos / LZX_PBR_STEP] = (uint16_t)((k >> KEY_CBAND_SHIFT) & 0xffffu);
         step_run[pos / LZX_PBR_STEP] = r;
     }
 }
@@ -1259,8 +1262,13 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     // (that was for a scatter pass with a launch of its own: sharing one with the staged-columns kernel, whose 128 KiB tile
     //  leaves room for one workgroup per CU either way, 16 Ki bands win there too -- C2 SpMV 0.076 -> 0.068 ms; 8 Ki bands
     //  remain for the two-chunk exchange on several ranks, where the passes are launched separately)
-    c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384) ? (u32)c->pb_cb_opt
-               : (c->xlen * sizeof(double) <= (16u << 20) && (c->overlap || c->fuse_opt == 0) ? 8192u : LZX_PB_CB);
+    // 18 Ki (144 KiB of the CU's 160 KiB): 4 % fewer (row, band) pairs -- values that cross the passes -- for 12 % more staging
+    // per unit; one rank only (the exchange layout cuts its chunks at 16 Ki boundaries).  Test shape pb_column_band = 16384 | 18432.
+    // Measured, every configuration in two consecutive processes (profiles/r4_wide_band.txt): 10 M-vertex R-MAT graph - 0.5 %
+    // (- 1.9 % with 18 Ki staged values as well), 1 M-vertex graph - 2.8 %, Erdos-Renyi 10 M - 2 .. 4 %: the default on one rank.
+    const bool wide_ok = c->world == 1 && !c->force_multi;
+    c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384 || (c->pb_cb_opt == LZX_PB_CB_WIDE && wide_ok)) ? (u32)c->pb_cb_opt
+               : (c->xlen * sizeof(double) <= (16u << 20) && (c->overlap || c->fuse_opt == 0) ? 8192u : (wide_ok ? LZX_PB_CB_WIDE : LZX_PB_CB));
     const u32 nb = (u32)((c->xlen + c->pb_cb - 1) / c->pb_cb);
     if (nb >= (1u << 16)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u column bands (limit 65535)", nb);
     // values per gather item / entries per plain band: every wavefront slot of the gather pass (2 workgroups of 8 per
@@ -1422,7 +1430,7 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     {
         u32 *d_rstart = nullptr, *d_band_pos = nullptr;
         LZX_TRY(ar.get(&d_rstart, (u64)nr + 1)); LZX_TRY(ar.get(&d_band_pos, (u64)nr + 1));
-        hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), d_sorted, total, 40u, nr, d_rstart);
+        hipLaunchKernelGGL(k_pb_bounds_u64, GRID(nr + 1), d_sorted, total, KEY_RBAND_SHIFT, nr, d_rstart);
         hipLaunchKernelGGL(k_pb_band_pos, GRID(nr + 1), d_rstart, d_runid, d_vpos, nr, total, (u32)len, d_band_pos);
         LZX_TRY(pb_download(st, d_band_pos, (size_t)nr + 1, rstart));
         ar.drop(d_rstart); ar.drop(d_band_pos);
@@ -1784,7 +1792,7 @@ int lzx_pb_prepare(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, con
 // can the staged-columns workgroups share the scatter pass's launch?  (not with the experimental forms of the pass)
 bool lzx_pb_can_fuse(const lzx_ctx *c)
 {
-    if (!c->pb || !(c->pb_cb == LZX_PB_CB || c->pb_cb == 8192)) return false;
+    if (!c->pb || !(c->pb_cb == LZX_PB_CB || c->pb_cb == 8192 || c->pb_cb == LZX_PB_CB_WIDE)) return false;
 #ifdef LZX_DEBUG_KNOBS
     if (c->phase_mask_opt & (4 | 8)) return false;
 #endif
@@ -1818,6 +1826,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
             if (scan) return ntc ? k_pb_scatter<8192, true, true> : k_pb_scatter<8192, true, false>;
             return ntc ? k_pb_scatter<8192, false, true> : k_pb_scatter<8192, false, false>;
         }
+        if (c->pb_cb == LZX_PB_CB_WIDE) return ntc ? k_pb_scatter<LZX_PB_CB_WIDE, true, true> : k_pb_scatter<LZX_PB_CB_WIDE, true, false>;
         if (scan) return ntc ? k_pb_scatter<LZX_PB_CB, true, true> : k_pb_scatter<LZX_PB_CB, true, false>;
         return ntc ? k_pb_scatter<LZX_PB_CB, false, true> : k_pb_scatter<LZX_PB_CB, false, false>;
     };
@@ -1828,13 +1837,15 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
     // rounds 2 and 3 (none was faster: profiles/NOTES.md) and removed in round 4
     auto scatter = [&](u32 u0, u32 u1, bool may_fuse) {
         if (u1 <= u0 && !(may_fuse && fuse && fused)) return;
-        if (may_fuse && fuse && fused && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192) && u0 == 0) {
+        if (may_fuse && fuse && fused && (c->pb_cb == LZX_PB_CB || c->pb_cb == 8192 || c->pb_cb == LZX_PB_CB_WIDE) && u0 == 0) {
             // the staged-columns workgroups share the launch of the scatter units (k_pb_scatter_spmv)
             using fused_fn = void (*)(const u32 *, u32, const uint4 *, const u32 *, const uint2 *, const u32 *, const double *, u64, double *, const SpmvArgs, const u32);
             fused_fn kf;
             if (c->pb_cb == 8192) {
                 if (scan) kf = ntc ? k_pb_scatter_spmv<8192, true, true> : k_pb_scatter_spmv<8192, true, false>;
                 else kf = ntc ? k_pb_scatter_spmv<8192, false, true> : k_pb_scatter_spmv<8192, false, false>;
+            } else if (c->pb_cb == LZX_PB_CB_WIDE) {
+                kf = ntc ? k_pb_scatter_spmv<LZX_PB_CB_WIDE, true, true> : k_pb_scatter_spmv<LZX_PB_CB_WIDE, true, false>;
             } else {
                 if (scan) kf = ntc ? k_pb_scatter_spmv<LZX_PB_CB, true, true> : k_pb_scatter_spmv<LZX_PB_CB, true, false>;
                 else kf = ntc ? k_pb_scatter_spmv<LZX_PB_CB, false, true> : k_pb_scatter_spmv<LZX_PB_CB, false, false>;

@@ -1,7 +1,7 @@
 // lzx_test_hooks.h -- test-only entry of liblzx.so (NOT part of the boundary in include/lzx.h; the drop-in classes never call it).
 // Forces the table shapes that large graphs get by themselves onto small test graphs, so that tests/ exercise the product
 // library's own kernels in every shape: "pb_reduce" (minimum run length of a reduced run; 0 = every run plain), "pb_target"
-// (values per gather item), "pb_unit" (entries per scatter unit), "pb_column_band" (8192 | 16384), "pb_run_align", "pb_taper",
+// (values per gather item), "pb_unit" (entries per scatter unit), "pb_column_band" (8192 | 16384 | 18432: the last on one rank only), "pb_run_align", "pb_taper",
 // "pb_dyn_share" (per cent of the gather pass left to its dynamic tail; 0 = every item dealt by the host), "pb_gather_grid" (at most this many gather workgroups),
 // "pb_gather_nt" (the gather pass's stream loads non-temporal 1 / cached 0, whatever the stream's size),
 // "pb_group" / "pb_group_force" (small row bands gathered one wavefront each), "narrow_slices", "tie_sort", "long_row",

@@ -24,6 +24,8 @@ def rel_inf(a, b):
 MODES = [dict(propagation_blocking=0), dict(propagation_blocking=1), dict(propagation_blocking=1, hub_entries=64),
          dict(propagation_blocking=1, pb_reduce=0),
          dict(propagation_blocking=1, hub_entries=512, pb_reduce=1500, pb_target=1024, pb_unit=4096, pb_column_band=16384),
+         # the 18 Ki column band (144 KiB tile, 15-bit column codes): reduced and plain runs
+         dict(propagation_blocking=1, hub_entries=512, pb_column_band=18432), dict(propagation_blocking=1, hub_entries=64, pb_reduce=16, pb_column_band=18432, pb_unit=4096),
          # the forms large graphs get by themselves, forced on small ones: narrow staged-only slices class by class, small row
          # bands gathered one wavefront each (eight per item), rows ranked by staged-column count first
          dict(propagation_blocking=1, hub_entries=64, narrow_slices=1, pb_group_force=8, pb_target=2048),
