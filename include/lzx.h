@@ -218,9 +218,7 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
 
 /* Options, to be set before the graph is handed over (the last two: any time; setting one abandons a decomposition that
  * was being advanced in chunks):
- *   "hub_entries"           x values of the highest-degree vertices staged in LDS by the SpMV (0 = none; default 8192, in blocked
- *                           mode 16384 -- 18432 on one rank from 4 Mi vertices -- or 1024 on graphs whose top columns hold < 1 % of
- *                           the entries)
+ *   "hub_entries"           x values of the highest-degree vertices staged in LDS by the SpMV (0 = none)
  *   "propagation_blocking"  1 / 0 force the two-pass blocked treatment of non-staged columns on / off
  *                           (default: on for graphs whose x does not fit the L2s); with it off the sliced-ELL
  *                           rows are summed in the reference's order and come out bit-identical to serial/
