@@ -976,7 +976,9 @@ int lzx_graph_prepare(lzx_ctx *c)
     //  phase.  In-process groups take it by default: every form of it is covered there, tests/test_gpu_parity.py.)
     const bool overlap_wanted = c->overlap_opt > 0 || (c->overlap_opt < 0 && c->comm_kind != 2);
     if ((world > 1 || c->force_multi) && pb && overlap_wanted && !c->xfp32) {
-        u32 x0 = round_up(std::max<u32>(c->xs / 8, (c->hub_real + world - 1) / world), LZX_PB_CB);
+        // (rounded to the column band the blocked passes will take -- lzx_pb.hip: 18 Ki unless 16 Ki is forced or x is small)
+        const u32 band = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384 || c->xlen * sizeof(double) <= (16u << 20)) ? LZX_PB_CB : LZX_PB_CB_WIDE;
+        u32 x0 = round_up(std::max<u32>(c->xs / 8, (c->hub_real + world - 1) / world), band);
         if (x0 < c->xs) {
             c->xs0 = x0;
             c->overlap = true;

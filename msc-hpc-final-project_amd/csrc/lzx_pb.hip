@@ -1263,12 +1263,14 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     //  leaves room for one workgroup per CU either way, 16 Ki bands win there too -- C2 SpMV 0.076 -> 0.068 ms; 8 Ki bands
     //  remain for the two-chunk exchange on several ranks, where the passes are launched separately)
     // 18 Ki (144 KiB of the CU's 160 KiB): 4 % fewer (row, band) pairs -- values that cross the passes -- for 12 % more staging
-    // per unit; one rank only (the exchange layout cuts its chunks at 16 Ki boundaries).  Test shape pb_column_band = 16384 | 18432.
+    // per unit.  Test shape pb_column_band = 16384 | 18432.
     // Measured, every configuration in two consecutive processes (profiles/r4_wide_band.txt): 10 M-vertex R-MAT graph - 0.5 %
     // (- 1.9 % with 18 Ki staged values as well), 1 M-vertex graph - 2.8 %, Erdos-Renyi 10 M - 2 .. 4 %: the default on one rank.
-    const bool wide_ok = c->world == 1 && !c->force_multi;
-    c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384 || (c->pb_cb_opt == LZX_PB_CB_WIDE && wide_ok)) ? (u32)c->pb_cb_opt
-               : (c->xlen * sizeof(double) <= (16u << 20) && (c->overlap || c->fuse_opt == 0) ? 8192u : (wide_ok ? LZX_PB_CB_WIDE : LZX_PB_CB));
+    // Rank shares gain as well (rank 0 of 2 / 4 / 8 on the 10 M-vertex graph: local SpMV - 3.8 / - 1.6 / - 3.0 %, profiles/r4_wide_band.txt);
+    // the exchange layout rounds chunk 0 to this width (lzx_graph.hip), and a band that straddles the chunk boundary -- 8 Ki bands
+    // chosen below for a small x -- simply waits for the second chunk.
+    c->pb_cb = (c->pb_cb_opt == 8192 || c->pb_cb_opt == 16384 || c->pb_cb_opt == LZX_PB_CB_WIDE) ? (u32)c->pb_cb_opt
+               : (c->xlen * sizeof(double) <= (16u << 20) && (c->overlap || c->fuse_opt == 0) ? 8192u : LZX_PB_CB_WIDE);
     const u32 nb = (u32)((c->xlen + c->pb_cb - 1) / c->pb_cb);
     if (nb >= (1u << 16)) LZX_FAIL(LZX_ERR_LIMIT, "propagation blocking: %u column bands (limit 65535)", nb);
     // values per gather item / entries per plain band: every wavefront slot of the gather pass (2 workgroups of 8 per

@@ -14,7 +14,7 @@ src.gen_rmat(scale, n, draws, 1234)
 rp, ci = src.get_graph_csr()
 src.close()
 for world in [int(w) for w in os.environ.get("RANK_PROBE_WORLDS", "1,2,4,8").split(",")]:
-    for opts in (dict(propagation_blocking=0), dict(sparse_exchange=0), dict()):
+    for opts in ([dict(), dict(pb_column_band=18432), dict(), dict(pb_column_band=18432)] if os.environ.get("RANK_PROBE_WIDE") else [dict(propagation_blocking=0), dict(sparse_exchange=0), dict()]):
         if world == 1:
             eng = pkg.Engine(0, **opts)
             eng.set_graph_csr(rp, ci)
