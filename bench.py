@@ -88,8 +88,11 @@ def pmc_traffic(workload: str, world: int):
         return None, None, None
 
 
-def cpu_baseline(eng, O, budget_s: float = 20.0):
-    """The oracle's restatement of serial/ (single thread) on the SAME graph, a bounded number of iterations."""
+def cpu_baseline(eng, O, budget_s: float = 10.0, omp_budget_s: float = 5.0):
+    """The oracle's restatement of serial/ (single thread) on the SAME graph, a bounded number of iterations -- and, beside it
+    ("optionally an OpenMP all-core SpMV number labelled as such"), the same loop with OpenMP over rows and
+    elements on the box's CPU share (oracle/lanczos_oracle_omp.c, kind "port-omp": a timing baseline whose inner products are
+    OpenMP reductions, not the reference's arithmetic)."""
     rp, ci = eng.get_graph_csr()
     n = len(rp) - 1
     x0 = np.ones(n)
@@ -100,9 +103,26 @@ def cpu_baseline(eng, O, budget_s: float = 20.0):
     t = time.perf_counter()
     O.lanczos(rp, ci, k, x0, want_q=False)
     dt = time.perf_counter() - t
-    return {"value": k / dt, "unit": "iter/s", "cores": 1, "kind": "port",
-            "sample": f"{k} Lanczos iterations of the same graph (oracle/lanczos_oracle.c, -O3 -ffp-contract=off as the reference builds, 1 thread, "
-                      f"{dt:.1f} s; host has {os.cpu_count()} hardware threads)"}
+    out = {"value": k / dt, "unit": "iter/s", "cores": 1, "kind": "port",
+           "sample": f"{k} Lanczos iterations of the same graph (oracle/lanczos_oracle.c, -O3 -ffp-contract=off as the reference builds, 1 thread, "
+                     f"{dt:.1f} s; host has {os.cpu_count()} hardware threads)"}
+    if omp_budget_s > 0:
+        try:
+            threads = max(1, min(int(os.environ.get("LZX_BENCH_OMP_THREADS", "16")), os.cpu_count() or 1))   # a one-GPU box's CPU share
+            O.lanczos_omp(rp, ci, 2, x0, threads=threads)                      # threads started, pages touched
+            t = time.perf_counter()
+            _, _, _, used = O.lanczos_omp(rp, ci, 2, x0)
+            per_iter = max((time.perf_counter() - t) / 2.0, 1e-6)
+            ko = int(max(2, min(50, omp_budget_s / per_iter)))
+            t = time.perf_counter()
+            O.lanczos_omp(rp, ci, ko, x0)
+            dto = time.perf_counter() - t
+            out["all_cores"] = {"value": ko / dto, "unit": "iter/s", "cores": used, "kind": "port-omp",
+                                "sample": f"{ko} iterations of the same loop with OpenMP over rows and elements (oracle/lanczos_oracle_omp.c; inner products "
+                                          f"are OpenMP reductions: another rounding than serial/'s), {used} threads, {dto:.1f} s"}
+        except Exception as exc:   # no OpenMP runtime on the box: the reference-faithful number stands alone
+            out["all_cores"] = {"value": None, "kind": "port-omp", "sample": f"not measured: {exc}"}
+    return out
 
 
 def main():
@@ -112,6 +132,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("LZX_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=10.0,
+                    help="seconds of single-thread oracle work the cpu_baseline leg may take (N = 1; the all-core leg takes half of it)")
     # N > 1 only.  rccl: ncclAllGather / grouped send-receive / ncclAllReduce (the default: the collective library is the
     # safer choice on a node this code has never seen).  ipc: the peer-window transport of csrc/lzx_ipc.hip (buffers mapped
     # across processes, pushed slices, mailbox all-reduce) -- measured on request until it has run on two physical GPUs.
@@ -185,6 +207,9 @@ def main():
         """(engine, seconds of graph build), or (None, 0) on EVERY rank when a local step failed on any of them.
         Local steps (handle creation, graph generation + reshaping) and the communicator's creation are guarded and
         agreed on with an all-reduce."""
+        # the library's default is 2 candidates for the value stream (lzx.h, "placement_trials"); the bench asks for the full seven
+        # and reports what each read (config.placement)
+        options = dict(options, placement_trials=int(os.environ.get("LZX_BENCH_PLACEMENT_TRIALS", "7")))
         if rehearse:
             options = dict(options, exchange_at_world_1=1)
         if shard_opt:
@@ -256,6 +281,35 @@ def main():
 
     x0 = np.ones(n)
 
+    def transport_self_check(e):
+        """N > 1, before anything is timed (round 5, ADVICE r4: the scored run may be the first time a transport moves data
+        between two physical GPUs, and alpha_0 against its closed form does not exercise the exchange at all).  Three products
+        through the exchange under test, none needing the oracle or the whole graph on a rank:
+          * A = A^T: z . (A x) = x . (A z) for two seeded random vectors -- an entry that arrived late, stale or in the wrong
+            place breaks it;
+          * A 1 is integer-valued and sums to nnz;
+          * every rank holds the same A x, bit for bit (a 64-bit checksum of its bytes, gathered).
+        Returns the figures for the JSON line; raises on a violation (the caller agrees on the outcome across ranks)."""
+        rng = np.random.default_rng(20260705)
+        x, z = rng.random(n), rng.random(n)
+        ax, az = e.spmv(x), e.spmv(z)
+        lhs, rhs = float(z @ ax), float(x @ az)
+        sym = abs(lhs - rhs) / max(abs(lhs), 1e-300)
+        ones = e.spmv(x0)
+        rows_exact = bool(np.array_equal(ones, np.rint(ones)) and float(ones.sum()) == float(e.info()["nnz"]))
+        words = ax.view(np.uint64)
+        digest = np.array([int(np.bitwise_xor.reduce(words)) & 0x7FFFFFFFFFFFFFFF, int(words.sum(dtype=np.uint64)) & 0x7FFFFFFFFFFFFFFF], dtype=np.int64)
+        same = True
+        if dist is not None:
+            mine = torch.from_numpy(digest).to(tdev)
+            everyone = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(everyone, mine)
+            same = all(torch.equal(t, everyone[0]) for t in everyone)
+        res = {"symmetry_rel": sym, "row_sums_exact": rows_exact, "ranks_bit_equal": same}
+        if not (sym < 1e-11 and rows_exact and same):
+            raise RuntimeError(f"transport self-check failed on rank {rank}: {res}")
+        return res
+
     def measure(e):
         """W untimed iterations (a decomposition of their own), then the workload's k-step decomposition is prepared and
         exactly K of its iterations run between barrier + synchronise on both sides, max over ranks; the other k - K follow
@@ -284,12 +338,15 @@ def main():
             elapsed = float(tmax.item())
             agg = torch.tensor([st["spmv_ms"], float(st["spmv_bytes"]), st["comm_ms"], st["vec_ms"]],
                                dtype=torch.float64, device=tdev)
-            mx = agg.clone()
+            mx, mn = agg.clone(), agg.clone()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-            m.update(spmv_ms_max=float(mx[0]), comm_ms=float(mx[2]), vec_ms=float(mx[3]), spmv_bytes_total=float(agg[1]))
+            m.update(spmv_ms_max=float(mx[0]), comm_ms=float(mx[2]), comm_ms_min=float(mn[2]), spmv_ms_min=float(mn[0]), vec_ms=float(mx[3]),
+                     spmv_bytes_total=float(agg[1]))
         else:
-            m.update(spmv_ms_max=st["spmv_ms"], comm_ms=st["comm_ms"], vec_ms=st["vec_ms"], spmv_bytes_total=float(st["spmv_bytes"]))
+            m.update(spmv_ms_max=st["spmv_ms"], comm_ms=st["comm_ms"], comm_ms_min=st["comm_ms"], spmv_ms_min=st["spmv_ms"], vec_ms=st["vec_ms"],
+                     spmv_bytes_total=float(st["spmv_bytes"]))
         t_out = time.perf_counter()
         alpha, beta, _ = e.lanczos_fetch(k_cfg)
         t_out = time.perf_counter() - t_out
@@ -308,6 +365,7 @@ def main():
             stream = e.bench_stream(2 << 30, 5)   # 2 GiB: eight times the Infinity Cache
         elapsed = m["elapsed"]
         spmv_avg_ms = m["spmv_ms_max"] / K
+        tried, place_us = gi["placement_tried"], gi["placement_us"]
         achieved = m["spmv_bytes_total"] / (spmv_avg_ms * 1e-3) / 1e9 if spmv_avg_ms > 0 else 0.0
         return {
             "metric": "lanczos_iterations_per_sec",
@@ -338,6 +396,12 @@ def main():
                              + (f"two chunks overlapping the SpMV, the second one sparse: each peer sends only what this rank's rows reference"
                                 if gi.get("exchange_chunk0") else "one all-gather") + ") + 1 two-double all-reduce" + (" through mailboxes in device memory" if args.transport == "ipc" else ""),
                 "transport": args.transport if world > 1 or launched else None,
+                "transport_fallback": tune.get("transport_fallback"),
+                "transport_self_check": m.get("self_check"),
+                # option placement_trials = 7 (this bench's choice; the library's default is 2): the value stream between the
+                # SpMV's two passes was allocated `tried` times at the hand-over, the SpMV timed with each, the fastest kept
+                "placement": {"tried": tried, "kept": gi["placement_kept"], "spmv_us_per_candidate": place_us,
+                              "chosen_us": min(place_us) if place_us else None, "worst_us": max(place_us) if place_us else None} if tried else None,
                 "exchange_tuning_ms_per_iter": dict(tune) or None,
                 "exchange_chunk0_doubles_per_rank": gi.get("exchange_chunk0", 0),
                 "graph_build_s": round(t_gen, 3),
@@ -374,6 +438,9 @@ def main():
                 "spmv_share_of_loop": m["spmv_ms_max"] / (elapsed * 1e3),
                 "vector_kernels_ms_per_iter": m["vec_ms"] / K,
                 "exchange_ms_per_iter": m["comm_ms"] / K,
+                # over the ranks (the figures above are the slowest rank's)
+                "exchange_ms_per_iter_max_min": [m["comm_ms"] / K, m["comm_ms_min"] / K],
+                "spmv_ms_per_iter_max_min": [m["spmv_ms_max"] / K, m["spmv_ms_min"] / K],
             },
         }
 
@@ -384,7 +451,7 @@ def main():
             sys.exit("bench.py: could not build the engine")
         out = line(eng, measure(eng), tune)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(eng, ge.load_oracle())
+            out["cpu_baseline"] = cpu_baseline(eng, ge.load_oracle(), args.cpu_budget_s, args.cpu_budget_s / 2)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     else:
         # Several ranks.  The exchange can run as one all-gather before the SpMV, or as two chunks overlapping the blocked
@@ -410,15 +477,33 @@ def main():
             return best / 6 * 1e3
 
         eng, t_gen = make_engine(overlap_exchange=0)
-        if eng is None and args.transport == "rccl" and not rehearse:
-            # the collective library would not start on this node: the transport that needs none (csrc/lzx_ipc.hip)
-            print(f"[bench rank {rank}] no engine over RCCL: trying the peer-window transport", file=sys.stderr, flush=True)
+        if eng is None and args.transport == "rccl" and not rehearse and os.environ.get("LZX_BENCH_IPC_FALLBACK") == "1":
+            # OPT-IN (round 5): the collective library would not start on this node and the caller allows the transport
+            # that needs none (csrc/lzx_ipc.hip).  Not the default: that transport has only ever run with all ranks on one GPU, and
+            # a scored run is no place for its first contact with xGMI.  Whatever transport runs is checked below before it is timed.
+            print(f"[bench rank {rank}] no engine over RCCL: trying the peer-window transport (LZX_BENCH_IPC_FALLBACK=1)", file=sys.stderr, flush=True)
             args.transport = "ipc"
             tune["transport_fallback"] = "rccl -> ipc"
             eng, t_gen = make_engine(overlap_exchange=0)
         if eng is None:
-            sys.exit(f"bench.py rank {rank}: could not build the engine (see stderr of the failing rank)")
+            sys.exit(f"bench.py rank {rank}: could not build the engine (see stderr of the failing rank; LZX_BENCH_IPC_FALLBACK=1 allows "
+                     f"the peer-window transport when RCCL cannot start)")
+
+        def checked(e, what):
+            """the transport's self-check on engine e; every rank learns the verdict before anybody enters the next collective"""
+            res, ok = None, True
+            try:
+                res = transport_self_check(e)
+            except Exception as exc:
+                print(f"[bench rank {rank}] {what}: {exc}", file=sys.stderr, flush=True)
+                ok = False
+            return res if all_ok(ok) else None
+
+        check_single = checked(eng, "single all-gather")
+        if check_single is None:
+            sys.exit(f"bench.py rank {rank}: the exchange failed its self-check (see stderr): nothing is measured over a transport that moves wrong data")
         m_single = measure(eng)
+        m_single["self_check"] = check_single
         tune["single"] = timed(eng)
         out = line(eng, m_single, tune) if rank == 0 else None
         import threading
@@ -441,7 +526,8 @@ def main():
             threading.Thread(target=watchdog, daemon=True).start()
             alt, _ = make_engine(overlap_exchange=1, sparse_exchange=1)
         # a rank count / graph that does not qualify for the overlapped mode on some rank: nothing to compare
-        if alt is not None and all_ok(bool(alt.info()["pb_entries"])):
+        check_alt = checked(alt, "overlapped / sparse exchange") if alt is not None and all_ok(bool(alt.info()["pb_entries"])) else None
+        if alt is not None and check_alt is not None:
             t_alt, ok = float("inf"), True
             try:
                 t_alt = timed(alt)
@@ -457,6 +543,7 @@ def main():
                     m_alt, ok = None, True
                     try:
                         m_alt = measure(alt)
+                        m_alt["self_check"] = check_alt
                     except Exception as exc:
                         print(f"[bench rank {rank}] overlapped exchange failed in the timed run: {exc}", file=sys.stderr, flush=True)
                         ok = False

@@ -80,6 +80,10 @@ typedef struct lzx_graph_info {
                                     exchange_slice with the plain all-gather; with the two-chunk exchange chunk 1 is
                                     sparse -- each peer sends only the entries this rank's rows reference -- and this
                                     is (world - 1) * exchange_chunk0 + what the peers pack for this rank */
+    uint32_t placement_tried;    /* option "placement_trials": allocations of the value stream timed at the hand-over (the
+                                    first one included; 0 = nothing to choose), */
+    uint32_t placement_kept;     /* the one kept, */
+    uint32_t placement_us[8];    /* and the SpMV time measured with each, in microseconds */
 } lzx_graph_info;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -270,7 +274,10 @@ int lzx_bench_stream(lzx_handle h, uint64_t bytes, uint32_t reps, double *read_g
  *                           SpMVs of set-up time each; results are bit-identical whichever wins).  Where the driver places
  *                           that one buffer decides up to 15 % of the SpMV on uniform graphs and 1-2 % on R-MAT ones for the
  *                           life of the allocation -- the reference's cudaMalloc blocks (cu_lanczos.cu:37-86) have no
- *                           counterpart.  Default 7 (fewer when the stream is several GB); 0 = take the first allocation.
+ *                           counterpart.  At most three candidates are alive at a time (the best so far, the one being timed,
+ *                           the last loser).  Default 2 (round 5: a library that may live inside a host framework does not
+ *                           multiply a buffer at its hand-over; bench.py asks for 7 and reports every candidate's time);
+ *                           at most 7; 0 = take the first allocation.
  *   "sharded_ingest"        s > 0: every hand-over entry point builds the graph WITHOUT ever holding all of it on one
  *                           device -- the loader of parallel-final/lib/adjMatrix.cc:21-46 for graphs beyond one card (SURVEY.md 7.1
  *                           step 7).  The whole-graph hand-over sorts all 2 m directed entries at once and leaves the whole CSR

@@ -23,7 +23,7 @@ PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "s
 # test-only shapes the product library accepts through lzx_test_set_shape (csrc/lzx_test_hooks.h): they select among code
 # paths the product contains (what large graphs get by themselves), so tests that force them still run liblzx.so
 SHAPE_OPTIONS = ("pb_reduce", "pb_target", "pb_unit", "pb_column_band", "pb_run_align", "pb_taper", "pb_dyn_share", "pb_carry_scan", "pb_scatter_nt", "pb_gather_grid", "pb_gather_nt", "spmv_wgs", "pb_group", "pb_group_force",
-                 "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1", "isolated_rows", "unnormalised_basis", "fuse_staged")
+                 "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1", "isolated_rows", "unnormalised_basis", "fuse_staged", "start_vector_scan")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -50,10 +50,13 @@ class LzxGraphInfo(ctypes.Structure):
                 ("pb_entries", ctypes.c_uint64), ("active_vertices", ctypes.c_uint64),
                 ("exchange_slice", ctypes.c_uint64), ("hub_entries", ctypes.c_uint32), ("world", ctypes.c_uint32), ("rank", ctypes.c_uint32),
                 ("reserved_", ctypes.c_uint32), ("pb_values", ctypes.c_uint64), ("pb_reduced_entries", ctypes.c_uint64),
-                ("exchange_chunk0", ctypes.c_uint64), ("exchange_recv", ctypes.c_uint64)]
+                ("exchange_chunk0", ctypes.c_uint64), ("exchange_recv", ctypes.c_uint64),
+                ("placement_tried", ctypes.c_uint32), ("placement_kept", ctypes.c_uint32), ("placement_us", ctypes.c_uint32 * 8)]
 
     def as_dict(self):
-        return {f: getattr(self, f) for f, _ in self._fields_}
+        d = {f: getattr(self, f) for f, _ in self._fields_}
+        d["placement_us"] = list(d["placement_us"])[:d["placement_tried"]]
+        return d
 
 
 # every symbol include/lzx.h declares: (name, restype, argtypes)

@@ -6,6 +6,7 @@
 // scalars alpha_j / beta_j never leave the device (as in the reference, where later kernels read
 // *alpha_d: parallel-final/lib/cu_lanczos.cu:108,113,123).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -148,6 +149,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "pb_gather_waves")) c->pb_gwaves_opt = value;
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
+    else if (!strcmp(name, "start_vector_scan")) c->x0_scan_opt = value;
 #endif
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
@@ -186,6 +188,8 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "isolated_rows")) c->iso_opt = value;
     else if (!strcmp(name, "unnormalised_basis")) c->basis_u_opt = value;
     else if (!strcmp(name, "fuse_staged")) c->fuse_opt = value;
+    // 0: the start vector always crosses PCIe and its norm is always the serial chain (what round 5's look at x0 is compared with)
+    else if (!strcmp(name, "start_vector_scan")) c->x0_scan_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_set_shape: unknown shape '%s'", name);
     return LZX_OK;
 }
@@ -200,6 +204,7 @@ extern "C" int lzx_test_get_shape(lzx_handle c, const char *name, int64_t *value
     else if (!strcmp(name, "gather_workgroups")) *value = c->pb ? c->pb_gather_grid : 0;
     else if (!strcmp(name, "placement_tried")) *value = c->place_tried;
     else if (!strcmp(name, "placement_kept")) *value = c->place_kept;
+    else if (!strcmp(name, "start_vector_was_constant")) *value = c->x0_was_constant ? 1 : 0;
     else if (!strncmp(name, "placement_us_", 13) && name[13] >= '0' && name[13] <= '7' && !name[14]) *value = (int64_t)(c->place_ms[name[13] - '0'] * 1e3f);
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_get_shape: unknown shape '%s'", name);
     return LZX_OK;
@@ -268,6 +273,9 @@ static int check_graphs(std::vector<lzx_ctx *> &cs)
         if (!c->d_row_ptr || !c->d_v) LZX_FAIL(LZX_ERR_STATE, "no graph has been handed over");
         if (c->n != cs[0]->n || c->nnz != cs[0]->nnz) LZX_FAIL(LZX_ERR_STATE, "handles hold different graphs");
     }
+    // an in-process group has no collective at the hand-over: its sparse exchange lists are compared here, pairwise, in length
+    // and in content (host memory; the other transports do it inside the hand-over, lzx_comm_check_sparse)
+    if (cs.size() > 1 && cs[0]->comm_kind == 1) LZX_TRY(lzx_comm_check_sparse_local(cs));
     return LZX_OK;
 }
 
@@ -379,6 +387,65 @@ static u64 spmv_algorithmic_bytes(const lzx_ctx *c)
     return 4ull * c->nnz_local + 4ull * ((u64)c->n_loc_real + 1) + 8ull * c->n + 8ull * c->n_loc_real;
 }
 
+// What one pass over the caller's start vector tells the hand-over (round 5: the reference-comparable figure times the
+// constructor, parallel-final/main.cu:104-116, and at n = 10 M the 80 MB pageable upload of x0 and the 10 M-term dependent
+// chain of ||x0||^2 were 6 ms of a 29 ms decomposition):
+//   constant  every entry equals x0[0] -- the reference's own start vector is ones (parallel-final/main.cu:79,
+//             serial/main.cc:79) -- so nothing needs to cross PCIe: the device fills the vector itself;
+//   exact     every entry is an integer of magnitude <= 2^26 and the squares add up to <= 2^53: every partial sum of
+//             serial/'s left-to-right loop (serial/lib/lanczos.cc:155-161) is then an exactly representable integer, the loop
+//             rounds nowhere, and the sum may be formed in any order -- in parallel -- with the same bits.
+// Several host threads, each its own stretch; a stretch gives up as soon as neither property can hold any more, so a
+// general vector costs one cache line's look, not a pass.
+struct X0Scan {
+    bool constant = false, exact = false;
+    double sum_sq = 0.0;
+};
+static X0Scan scan_start_vector(const double *x0, u64 n)
+{
+    X0Scan out;
+    if (n == 0) return out;
+    const u32 hw = std::max(1u, std::thread::hardware_concurrency());
+    const u32 T = (u32)std::min<u64>(std::min<u32>(8u, hw), n / (1u << 18) + 1);
+    std::vector<double> part(T, 0.0);
+    std::atomic<bool> all_const{true}, all_int{true};
+    const double first = x0[0];
+    auto work = [&](u32 t) {
+        const u64 a = n * t / T, b = n * (t + 1) / T;
+        double acc = 0.0;
+        bool cst = true, itg = true;
+        for (u64 i0 = a; i0 < b; i0 += 4096) {
+            const u64 i1 = std::min<u64>(b, i0 + 4096);
+            for (u64 i = i0; i < i1; ++i) {
+                const double v = x0[i];
+                cst &= v == first;
+                itg &= std::fabs(v) <= 67108864.0 && v == std::nearbyint(v);   // (NaN fails both)
+                acc += v * v;
+            }
+            if (!cst) all_const.store(false, std::memory_order_relaxed);
+            if (!itg) all_int.store(false, std::memory_order_relaxed);
+            if (!all_const.load(std::memory_order_relaxed) && !all_int.load(std::memory_order_relaxed)) return;
+        }
+        part[t] = acc;
+    };
+    {
+        std::vector<std::thread> th;
+        for (u32 t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    out.constant = all_const.load();
+    if (all_int.load()) {
+        double s = 0.0;
+        for (u32 t = 0; t < T; ++t) s += part[t];   // integers: exact as long as the total is
+        if (s <= 9007199254740992.0) {
+            out.exact = true;
+            out.sum_sq = s;
+        }
+    }
+    return out;
+}
+
 // Upload x0, normalise it into q_0 and size the resident basis for k vectors.
 static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, double *x_norm_out)
 {
@@ -413,15 +480,20 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161) -- one dependent chain of
     // n additions (7 ms at n = 10 M), on a helper thread while this one sizes the basis, clears it and uploads x0 (a pageable
     // copy that blocks its caller for about as long)
-    double ss = 0.0;
+    // (round 5) unless one look at x0 shows that the sum is exact in any order -- then it was formed by scan_start_vector's
+    // threads -- and, for a constant vector, that there is nothing to upload
+    const X0Scan scan = c0->x0_scan_opt != 0 ? scan_start_vector(x0, n) : X0Scan{};
+    double ss = scan.sum_sq;
     struct Joiner {
         std::thread t;
         ~Joiner() { if (t.joinable()) t.join(); }
-    } norm_thread{std::thread([&ss, x0, n]() {
-        double acc = 0.0;
-        for (u64 i = 0; i < n; ++i) acc += x0[i] * x0[i];
-        ss = acc;
-    })};
+    } norm_thread;
+    if (!scan.exact)
+        norm_thread.t = std::thread([&ss, x0, n]() {
+            double acc = 0.0;
+            for (u64 i = 0; i < n; ++i) acc += x0[i] * x0[i];
+            ss = acc;
+        });
 
     for (lzx_ctx *c : cs) {
         LZX_HIP(hipSetDevice(c->device));
@@ -434,9 +506,11 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
             if (k > 1)
                 LZX_HIP(hipMemset2DAsync(c->d_Q + c->ldq + c->n_loc_pad, sizeof(double) * c->ldq, 0, sizeof(double) * LZX_TAIL, k - 1, c->stream));
         }
-        LZX_HIP(hipMemcpyAsync(c->d_io, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        if (scan.constant) LZX_TRY(lzx_launch_fill(c, c->d_io, x0[0], n));
+        else LZX_HIP(hipMemcpyAsync(c->d_io, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        c->x0_was_constant = scan.constant;
     }
-    norm_thread.t.join();
+    if (norm_thread.t.joinable()) norm_thread.t.join();
     const double x_norm = std::sqrt(ss);
     if (x_norm_out) *x_norm_out = x_norm;
     for (lzx_ctx *c : cs) {

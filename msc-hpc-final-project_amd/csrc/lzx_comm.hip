@@ -378,19 +378,63 @@ int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slic
 
 // One-off check when the graph is reshaped (RCCL transport): every rank derives by itself what it sends to and receives
 // from each peer in the sparse chunk (k_sx_mark + a scan) -- nothing is negotiated, so a disagreement would only show as
-// a grouped ncclSend / ncclRecv that never completes.  All ranks gather everybody's [send counts | receive counts] and
-// check EVERY pair (what p packs for q == what q expects from p): all of them reach the same verdict, so a mismatch is an
-// error on every rank at once (LZX_ERR_STATE), never a hang.
+// a grouped ncclSend / ncclRecv that never completes, or (equal lengths, other members) as a silently wrong product.  All
+// ranks gather everybody's [send counts | receive counts | send hashes | receive hashes] and check EVERY pair (what p packs
+// for q == what q expects from p, in length and in content): all of them reach the same verdict, so a mismatch is an error on
+// every rank at once (LZX_ERR_STATE), never a hang.
+void lzx_sx_check_message(const lzx_ctx *c, std::vector<u32> &mine)
+{
+    const u32 world = (u32)c->world;
+    mine.assign(6 * (size_t)world, 0u);
+    for (u32 p = 0; p < world; ++p) {
+        mine[p] = c->sx_send_off[p + 1] - c->sx_send_off[p];
+        mine[world + p] = c->sx_recv_off[p + 1] - c->sx_recv_off[p];
+        const u64 hs = p < c->sx_send_hash.size() ? c->sx_send_hash[p] : 0, hr = p < c->sx_recv_hash.size() ? c->sx_recv_hash[p] : 0;
+        mine[2 * world + 2 * p] = (u32)hs;
+        mine[2 * world + 2 * p + 1] = (u32)(hs >> 32);
+        mine[4 * world + 2 * p] = (u32)hr;
+        mine[4 * world + 2 * p + 1] = (u32)(hr >> 32);
+    }
+}
+
+int lzx_sx_check_pairs(const std::vector<u32> &all, u32 world)
+{
+    const size_t M = 6 * (size_t)world;
+    for (u32 p = 0; p < world; ++p)
+        for (u32 q = 0; q < world; ++q) {
+            const u32 *mp = all.data() + (size_t)p * M, *mq = all.data() + (size_t)q * M;
+            const u32 sends = mp[q], expects = mq[world + p];
+            if (sends != expects)
+                LZX_FAIL(LZX_ERR_STATE, "sparse exchange: rank %u packs %u entries for rank %u, which expects %u", p, sends, q, expects);
+            if (mp[2 * world + 2 * q] != mq[4 * world + 2 * p] || mp[2 * world + 2 * q + 1] != mq[4 * world + 2 * p + 1])
+                LZX_FAIL(LZX_ERR_STATE, "sparse exchange: rank %u packs %u entries for rank %u, which expects as many but OTHER ones "
+                                        "(the matrix handed over is not symmetric, or the ranks hold different graphs)", p, sends, q);
+        }
+    return LZX_OK;
+}
+
+int lzx_comm_check_sparse_local(std::vector<lzx_ctx *> &cs)
+{
+    const u32 world = (u32)cs.size();
+    if (world < 2 || !cs[0]->sparse) return LZX_OK;
+    std::vector<u32> all, mine;
+    for (lzx_ctx *c : cs) {
+        if (!c->sparse || (u32)c->world != world || c->sx_send_off.size() != world + 1 || c->sx_recv_off.size() != world + 1)
+            LZX_FAIL(LZX_ERR_STATE, "sparse exchange: the handles of the group were handed graphs with different exchange options");
+        lzx_sx_check_message(c, mine);
+        all.insert(all.end(), mine.begin(), mine.end());
+    }
+    return lzx_sx_check_pairs(all, world);
+}
+
 int lzx_comm_check_sparse(lzx_ctx *c)
 {
     if (c->comm_kind == 3 && c->sparse) return lzx_comm_ipc_check_sparse(c);
     if (c->comm_kind != 2 || !c->sparse) return LZX_OK;
     const u32 world = (u32)c->world;
-    std::vector<u32> mine(2 * (size_t)world), all(2 * (size_t)world * world);
-    for (u32 p = 0; p < world; ++p) {
-        mine[p] = c->sx_send_off[p + 1] - c->sx_send_off[p];
-        mine[world + p] = c->sx_recv_off[p + 1] - c->sx_recv_off[p];
-    }
+    std::vector<u32> mine;
+    lzx_sx_check_message(c, mine);
+    std::vector<u32> all(mine.size() * world);
     u32 *d = nullptr;
     LZX_HIP(hipSetDevice(c->device));
     // the staging buffer is a rank-local allocation in front of a collective: agree on it first (a rank that could not
@@ -414,13 +458,7 @@ int lzx_comm_check_sparse(lzx_ctx *c)
     (void)hipFree(d);
     if (r != ncclSuccess) LZX_FAIL(LZX_ERR_COMM, "sparse exchange check: %s", g_rccl.GetErrorString(r));
     LZX_HIP(e);
-    for (u32 p = 0; p < world; ++p)
-        for (u32 q = 0; q < world; ++q) {
-            const u32 sends = all[(size_t)p * 2 * world + q], expects = all[(size_t)q * 2 * world + world + p];
-            if (sends != expects)
-                LZX_FAIL(LZX_ERR_STATE, "sparse exchange: rank %u packs %u entries for rank %u, which expects %u", p, sends, q, expects);
-        }
-    return LZX_OK;
+    return lzx_sx_check_pairs(all, world);
 }
 
 // N4 (SURVEY 8 f): the per-iteration all-gather with the slices rounded to fp32 -- half the bytes on the wire.  Every

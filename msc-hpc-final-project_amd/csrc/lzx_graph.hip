@@ -58,6 +58,8 @@ int lzx_graph_release(lzx_ctx *c)
     c->xc1 = 0;
     c->sx_recv_off.clear();
     c->sx_send_off.clear();
+    c->sx_send_hash.clear();
+    c->sx_recv_hash.clear();
     dev_free(c->d_slice_off);
     dev_free(c->d_slice_w);
     dev_free(c->d_slice_perm);
@@ -1091,6 +1093,25 @@ int lzx_graph_prepare(lzx_ctx *c)
                            c->hub_real, c->xs0, L1, c->n_loc_pad, d_ref, d_pos, c->d_sx_map);
         hipLaunchKernelGGL(k_sx_lists, dim3((u32)((cnt + 255) / 256)), dim3(256), 0, st, d_want, d_spos, cnt, L1, c->xs0, c->d_sx_send_idx);
         SX_HIP(hipStreamSynchronize(st));
+        // What travels is agreed on by CONTENT, not only by length (round 5, ADVICE r4: with the sharded hand-over the send lists come
+        // from this rank's own rows through the matrix's symmetry, so a caller's CSR that is not symmetric could give lists of the
+        // right lengths and the wrong members): one order-dependent 64-bit hash per peer of what this rank packs for it and of
+        // what it expects from it, compared pairwise beside the counts (lzx_comm_check_sparse; in-process groups: lzx_api.hip).
+        {
+            std::vector<u32> h_idx(c->sx_send_off[world]), h_map(c->xc1);
+            if (!h_idx.empty()) SX_HIP(hipMemcpy(h_idx.data(), c->d_sx_send_idx, sizeof(u32) * h_idx.size(), hipMemcpyDeviceToHost));
+            if (!h_map.empty()) SX_HIP(hipMemcpy(h_map.data(), c->d_sx_map, sizeof(u32) * h_map.size(), hipMemcpyDeviceToHost));
+            c->sx_send_hash.assign(world, 0);
+            c->sx_recv_hash.assign(world, 0);
+            for (u32 p = 0; p < world; ++p) {
+                u64 hs = 0, hr = 0;
+                for (u32 i = c->sx_send_off[p]; i < c->sx_send_off[p + 1]; ++i) hs += lzx_mix64((u64)h_idx[i] + ((u64)(i - c->sx_send_off[p]) << 32));
+                for (u32 i = c->sx_recv_off[p]; i < c->sx_recv_off[p + 1]; ++i)
+                    hr += lzx_mix64((u64)(h_map[i] - p * c->n_loc_pad) + ((u64)(i - c->sx_recv_off[p]) << 32));
+                c->sx_send_hash[p] = hs;
+                c->sx_recv_hash[p] = hr;
+            }
+        }
         sx_free();
 #undef SX
 #undef SX_HIP
@@ -1642,5 +1663,8 @@ extern "C" int lzx_get_graph_info(lzx_handle c, lzx_graph_info *o)
     o->exchange_slice = c->world > 1 ? c->xs : 0;
     o->world = (uint32_t)c->world;
     o->rank = (uint32_t)c->rank;
+    o->placement_tried = c->place_tried;
+    o->placement_kept = c->place_kept;
+    for (u32 t = 0; t < 8; ++t) o->placement_us[t] = t < c->place_tried ? (uint32_t)(c->place_ms[t] * 1e3f) : 0u;
     return LZX_OK;
 }

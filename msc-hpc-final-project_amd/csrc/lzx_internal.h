@@ -83,6 +83,7 @@ struct lzx_ipc_state {
     u64 seq[2] = {0, 0};               // last sequence number used on the main / the exchange stream's channel
     u64 mail_seq = 0, board_seq = 0;
     u64 deadline = 0;                  // ticks of the 100 MHz wall clock a wait may take
+    bool broken = false;               // a deadline expired (here, or on a peer that then poisoned this window): every later collective fails at once
     struct Buf { void *mine = nullptr; size_t bytes = 0; void *peer[64] = {}; size_t peer_bytes[64] = {}; bool opened[64] = {}; } buf[LZX_IPC_BUFS];
     std::vector<u64> sx_dst_off;       // [world] where this rank's packed piece starts inside every peer's chunk 1
 };
@@ -159,6 +160,7 @@ struct lzx_ctx {
     u64 xc1 = 0;                       // packed length of chunk 1 on this rank (all peers' segments)
     std::vector<u32> sx_recv_off;      // [world + 1] offsets of the peers' segments inside the packed chunk 1
     std::vector<u32> sx_send_off;      // [world + 1] offsets of what goes to each peer inside d_sx_sendbuf
+    std::vector<u64> sx_send_hash, sx_recv_hash;   // [world] order-dependent hash of the local indices packed for / expected from every peer
     u32 *d_sx_send_idx = nullptr;      // [sx_send_off[world]] local row index (>= xs0) of every packed entry, peer-major
     double *d_sx_sendbuf = nullptr;    // [sx_send_off[world]]
     u32 *d_sx_map = nullptr;           // [xc1] packed chunk-1 position -> position in the hand-over layout (p * n_loc_pad + l)
@@ -301,8 +303,11 @@ struct lzx_ctx {
     int64_t ref_order_opt = -1;
     // Option placement_trials (blocked mode): at the end of a graph hand-over the value stream between the two passes is
     // allocated this many more times, the SpMV timed with each, the fastest kept -- where the driver puts that buffer
-    // decides 15 % of the Erdos-Renyi SpMV and 1-2 % of the R-MAT one (lzx_pb.hip: lzx_pb_place_values).  -1: default (7, fewer for streams of several GB), 0: off.
+    // decides 15 % of the Erdos-Renyi SpMV and 1-2 % of the R-MAT one (lzx_pb.hip: lzx_pb_place_values).  -1: default (2), 0: off, at most 7.
     int64_t place_opt = -1;
+    // test shape start_vector_scan (lzx_api.hip: scan_start_vector): 0 = x0 always crosses PCIe, its norm always the serial chain
+    int64_t x0_scan_opt = -1;
+    bool x0_was_constant = false;      // the last prepared start vector was filled on the device, not uploaded
     u32 place_tried = 0;               // allocations timed at the last hand-over (incl. the first one), and their SpMV times
     float place_ms[8] = {};
     u32 place_kept = 0;
@@ -383,6 +388,7 @@ int lzx_launch_axpy_norm(lzx_ctx *c, double *v, const double *qj, const double *
 int lzx_launch_scale(lzx_ctx *c, const double *v, double *q_next, const double *partials_in,
                      u32 np_in, double *beta_out);
 int lzx_launch_permute_in(lzx_ctx *c, const double *io_old_order, double *full, double scale);
+int lzx_launch_fill(lzx_ctx *c, double *out, double value, u64 count);
 int lzx_launch_permute_out(lzx_ctx *c, const double *full, double *io_old_order, const double *div = nullptr);   // div: device scalar every entry is divided by
 // hand-over layout (stride n_loc_pad) -> exchange layout (stride xs): the active prefix of every rank's slice
 int lzx_launch_relayout(lzx_ctx *c, const double *io_layout, double *exchange_layout);
@@ -402,6 +408,18 @@ int lzx_launch_widen_col(lzx_ctx *c, u32 col, double *out);
 
 // ---- lzx_comm.hip ----
 // does the Lanczos loop exchange vectors / reduce scalars through the communicator?
+// splitmix64 finaliser: the hash of the sparse exchange's index lists (lzx_graph.hip, lzx_comm_check_sparse)
+inline u64 lzx_mix64(u64 z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// One rank's message of the sparse-exchange check, 6 * world words: [send counts | receive counts | send hashes (lo, hi) | receive
+// hashes (lo, hi)]; lzx_sx_check_pairs: every pair of ranks agrees on how many entries travel AND on which ones, or an error that
+// is the same on every rank (all of them hold all messages).
+void lzx_sx_check_message(const lzx_ctx *c, std::vector<u32> &mine);
+int lzx_sx_check_pairs(const std::vector<u32> &all, u32 world);
 inline bool lzx_exchanges(const lzx_ctx *c) { return c->world > 1 || (c->force_multi && c->comm_kind >= 2); }
 int lzx_comm_allreduce_sum(std::vector<lzx_ctx *> &cs, u32 slot, u32 count = 1);   // d_scal[slot .. slot+count) on every handle
 // peers_idle: the caller knows that no rank still reads what the gather overwrites (the loop: an all-reduce lies between
@@ -413,7 +431,8 @@ int lzx_comm_allgather(std::vector<lzx_ctx *> &cs, const double *const *src_loc,
 // own slice of the new vector) and the packed pieces land in the peers' d_xbuf behind chunk 0; on the exchange streams
 int lzx_comm_sparse_chunk1(std::vector<lzx_ctx *> &cs, const double *const *slice_loc, bool peers_idle = false);
 int lzx_launch_sx_pack(lzx_ctx *c, const double *slice_loc, hipStream_t st);
-int lzx_comm_check_sparse(lzx_ctx *c);   // RCCL: all ranks' send / receive counts of the sparse chunk agree pairwise, or LZX_ERR_STATE everywhere
+int lzx_comm_check_sparse(lzx_ctx *c);   // RCCL, peer windows: all ranks' send / receive lists of the sparse chunk agree pairwise (lengths and content hashes), or LZX_ERR_STATE everywhere
+int lzx_comm_check_sparse_local(std::vector<lzx_ctx *> &cs);   // the same for the handles of an in-process group (host memory, no collective)
 // RCCL: every rank learns whether a rank-LOCAL step (an allocation, a sort, ...) failed on ANY rank -- a 1-value all-reduce
 // (min) on the handle's pre-allocated scalars -- before any of them enters the next collective; other transports: *all_ok = ok.
 int lzx_comm_agree(lzx_ctx *c, bool ok, bool *all_ok);

@@ -14,6 +14,12 @@
 // Replaces, like the other transports, parallel-two-cards/lib/cu_lanczos.cu:62-67 (peer access), 125 / 158 (the two
 // cudaMemcpyPeer of every iteration) and the host round trips of its scalar reductions (:104-105, 119-120).
 //
+// Failure model (round 5): a deadline that expires is FATAL for the communicator.  The rank that saw it marks its
+// state broken (every later collective fails at once with LZX_ERR_COMM, nothing is retried on advanced sequence numbers) and
+// poisons the err word of every peer's window, which every spinning wavefront polls beside its flag: the peers fail fast
+// instead of meeting a board message or a mailbox value of a different operation.  Board messages carry the operation's tag
+// and the board's sequence number; a mismatch is the same fatal error.
+//
 // Why the flags may share a stream's channel: every signal of a rank on one stream is issued in that stream's order and
 // carries a number one higher than the last, so "flag >= s" also says that everything the rank put before s has landed.
 // Why two mailbox / board parities suffice: a rank can post operation s + 2 only after it completed s + 1, which needed
@@ -21,6 +27,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 
 #include "lzx_internal.h"
@@ -30,7 +38,7 @@
 namespace {
 
 constexpr u32 IPC_MAGIC = 0x4c5a5849u;   // "LZXI"
-constexpr u32 IPC_BOARD = 1024;          // bytes one rank can post in a host-level all-gather
+constexpr u32 IPC_BOARD = 2048;          // bytes one rank can post in a host-level all-gather (the sparse check: 6 * 64 words + head)
 
 struct MailSlot {
     double v[8];
@@ -54,6 +62,7 @@ struct Blob {   // what lzx_comm_ipc_export hands to the peers (LZX_IPC_BLOB byt
     u32 magic, finegrained;
     int pid, device;
     u64 ptr;    // the window's address in the exporting process (ranks of ONE process use it directly)
+    u64 nonce;  // per-process random number: a pid alone may repeat across PID namespaces or after reuse
     hipIpcMemHandle_t handle;
 };
 static_assert(sizeof(Blob) <= LZX_IPC_BLOB, "blob fits");
@@ -65,9 +74,29 @@ struct BufMsg {   // one exported receive buffer on the board
 struct PublishMsg {
     u32 ok, n_bufs;
     int pid, pad;
+    u64 nonce;
     BufMsg buf[LZX_IPC_BUFS];
 };
-static_assert(sizeof(PublishMsg) <= IPC_BOARD, "publish message fits the board");
+struct BoardHead {   // in front of every board message: which collective this is, and the how-many-th of the board
+    u32 tag, seq;
+};
+enum : u32 { TAG_AGREE = 0xa1u, TAG_PUBLISH = 0xb2u, TAG_SPARSE = 0xc3u };
+static_assert(sizeof(PublishMsg) + sizeof(BoardHead) <= IPC_BOARD, "publish message fits the board");
+
+// this process's nonce (Blob, PublishMsg): same pid AND same nonce = a rank of this very process, whose pointers may be used as they are
+u64 process_nonce()
+{
+    static const u64 v = [] {
+        u64 x = 0;
+        if (FILE *f = fopen("/dev/urandom", "rb")) {
+            if (fread(&x, sizeof x, 1, f) != 1) x = 0;
+            fclose(f);
+        }
+        x ^= (u64)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull ^ ((u64)getpid() << 32);
+        return x ? x : 1ull;
+    }();
+    return v;
+}
 
 struct FlagPeers { unsigned long long *flag[64]; };
 struct MailPeersIpc { MailSlot *slot[64]; };
@@ -80,13 +109,15 @@ template <typename T> struct PutArgs {
 // The polls are RELAXED system-scope loads (they bypass the caches by themselves); the one acquire fence follows the successful
 // poll.  An acquire per poll would invalidate this XCD's L2 every few hundred nanoseconds -- under an SpMV that is running on the
 // other stream at that very moment.
-__device__ __forceinline__ bool spin_until(const unsigned long long *flag, u64 seq, u64 deadline_ticks)
+// err: this rank's own err word -- set by an expired wait of this rank or poisoned by a peer that gave up (lzx_comm_ipc_check): either
+// ends the spin at once.
+__device__ __forceinline__ bool spin_until(const unsigned long long *flag, u64 seq, u64 deadline_ticks, const unsigned int *err)
 {
     const u64 t0 = wall_clock64();
     bool ok = true;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > deadline_ticks) { ok = false; break; }
+        if (wall_clock64() - t0 > deadline_ticks || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) { ok = false; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     return ok;
@@ -99,7 +130,14 @@ __global__ void __launch_bounds__(64) k_ipc_signal(FlagPeers peers, u32 world, u
 
 __global__ void __launch_bounds__(64) k_ipc_wait(const unsigned long long *flags, u32 world, u64 seq, u64 deadline_ticks, unsigned int *err)
 {
-    if (threadIdx.x < world && !spin_until(flags + threadIdx.x, seq, deadline_ticks)) atomicCAS(err, 0u, 1u + threadIdx.x);
+    if (threadIdx.x < world && !spin_until(flags + threadIdx.x, seq, deadline_ticks, err)) atomicCAS(err, 0u, 1u + threadIdx.x);
+}
+
+// a rank that gave up tells everybody: err word of every peer's window (the peers' spinning wavefronts poll it)
+struct ErrPeers { unsigned int *err[64]; };
+__global__ void __launch_bounds__(64) k_ipc_poison(ErrPeers peers, u32 world, u32 me)
+{
+    if (threadIdx.x < world && threadIdx.x != me) atomicCAS_system(peers.err[threadIdx.x], 0u, 0x80000000u | (1u + me));
 }
 
 // WT: the data as write-through stores (system-scope relaxed atomic stores: nothing stays dirty in this XCD's L2, so the
@@ -141,7 +179,9 @@ __global__ void __launch_bounds__(LZX_VEC_BLOCK) k_ipc_allreduce(MailPeersIpc ou
     __shared__ double vals[64][8];
     __shared__ double sh[4];
     __shared__ double own[8];
+    __shared__ u32 timed_out;
     const u32 p = threadIdx.x;
+    if (p == 0) timed_out = 0u;
     if (pa) {
         const double a = block_sum_fixed_256(pa, na, sh);
         __syncthreads();
@@ -155,11 +195,14 @@ __global__ void __launch_bounds__(LZX_VEC_BLOCK) k_ipc_allreduce(MailPeersIpc ou
         MailSlot *o = out.slot[p];
         for (u32 i = 0; i < count; ++i) o->v[i] = own[i];
         __hip_atomic_store(&o->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (!spin_until(&in[p].seq, seq, deadline_ticks)) atomicCAS(err, 0u, 1u + p);
+        if (!spin_until(&in[p].seq, seq, deadline_ticks, err)) {
+            atomicCAS(err, 0u, 1u + p);
+            timed_out = 1u;
+        }
         for (u32 i = 0; i < count; ++i) vals[p][i] = __hip_atomic_load(&in[p].v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
-    if (p < count) {
+    if (p < count && !timed_out) {   // a slot that never arrived holds an older operation's values: nothing is written
         double s = vals[0][p];
         for (u32 q = 1; q < world; ++q) s = op == 0 ? s + vals[q][p] : (vals[q][p] < s ? vals[q][p] : s);
         scal[p] = s;
@@ -179,6 +222,14 @@ u64 deadline_ticks()
 
 hipStream_t pick(lzx_ctx *c, bool s2) { return s2 ? c->stream2 : c->stream; }
 
+// a deadline expired earlier (here or, poisoned, on a peer): the sequence numbers of the ranks no longer describe the same
+// operations, so nothing more is queued on this communicator
+#define IPC_ALIVE(c)                                                                                                             \
+    do {                                                                                                                         \
+        if ((c)->ipc->broken)                                                                                                    \
+            LZX_FAIL(LZX_ERR_COMM, "peer windows: the communicator is broken (a rank did not arrive within the deadline earlier); destroy the handles and wire new ones"); \
+    } while (0)
+
 FlagPeers flag_peers(lzx_ctx *c, bool s2)
 {
     FlagPeers f{};
@@ -188,6 +239,7 @@ FlagPeers flag_peers(lzx_ctx *c, bool s2)
 
 int queue_wait(lzx_ctx *c, bool s2, u64 seq)
 {
+    IPC_ALIVE(c);
     Window *w = static_cast<Window *>(c->ipc->win);
     hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, pick(c, s2), w->flag[s2 ? 1 : 0], (u32)c->world, seq, c->ipc->deadline, &w->err);
     LZX_HIP(hipGetLastError());
@@ -197,6 +249,7 @@ int queue_wait(lzx_ctx *c, bool s2, u64 seq)
 // every rank has queued everything before this point on that stream: signal, then wait for everybody's signal
 int queue_barrier(lzx_ctx *c, bool s2)
 {
+    IPC_ALIVE(c);
     const u64 seq = ++c->ipc->seq[s2 ? 1 : 0];
     hipLaunchKernelGGL(k_ipc_signal, dim3(1), dim3(64), 0, pick(c, s2), flag_peers(c, s2), (u32)c->world, seq);
     LZX_HIP(hipGetLastError());
@@ -205,6 +258,7 @@ int queue_barrier(lzx_ctx *c, bool s2)
 
 template <typename T> int queue_put(lzx_ctx *c, bool s2, const PutArgs<T> &a)
 {
+    IPC_ALIVE(c);
     u64 total = 0;
     for (int p = 0; p < c->world; ++p) total += a.cnt[p];
     static const int grid_env = getenv("LZX_IPC_PUT_GRID") ? atoi(getenv("LZX_IPC_PUT_GRID")) : 0;
@@ -220,16 +274,23 @@ template <typename T> int queue_put(lzx_ctx *c, bool s2, const PutArgs<T> &a)
     return queue_wait(c, s2, seq);
 }
 
-// host-level all-gather of <= IPC_BOARD bytes per rank through the windows (main stream; returns after a synchronisation)
-int host_allgather(lzx_ctx *c, const void *mine, size_t bytes, std::vector<unsigned char> &all)
+void mark_broken(lzx_ctx *c);
+
+// host-level all-gather of <= IPC_BOARD - 8 bytes per rank through the windows (main stream; returns after a synchronisation).
+// Every message is headed by the operation's tag and the board's sequence number: ranks that have fallen out of step -- one of
+// them retried after a failure the other never saw -- read a mismatch here, not each other's bytes as something they are not.
+int host_allgather(lzx_ctx *c, u32 tag, const void *mine, size_t bytes, std::vector<unsigned char> &all)
 {
-    if (bytes > IPC_BOARD) LZX_FAIL(LZX_ERR_LIMIT, "peer windows: a board message of %zu bytes", bytes);
+    if (bytes + sizeof(BoardHead) > IPC_BOARD) LZX_FAIL(LZX_ERR_LIMIT, "peer windows: a board message of %zu bytes", bytes);
+    IPC_ALIVE(c);
     lzx_ipc_state *s = c->ipc;
     Window *w = static_cast<Window *>(s->win);
+    const BoardHead head{tag, (u32)s->board_seq};
     const u32 parity = (u32)(s->board_seq++ & 1u);
-    const size_t words = (bytes + 7) / 8;
+    const size_t words = (sizeof(BoardHead) + bytes + 7) / 8;
     unsigned char tmp[IPC_BOARD] = {};
-    memcpy(tmp, mine, bytes);
+    memcpy(tmp, &head, sizeof head);
+    memcpy(tmp + sizeof head, mine, bytes);
     LZX_HIP(hipSetDevice(c->device));
     LZX_HIP(hipMemcpyAsync(w->stage, tmp, words * 8, hipMemcpyHostToDevice, c->stream));
     PutArgs<unsigned long long> a{};
@@ -244,8 +305,30 @@ int host_allgather(lzx_ctx *c, const void *mine, size_t bytes, std::vector<unsig
     LZX_HIP(hipMemcpyAsync(raw.data(), w->board[parity], raw.size(), hipMemcpyDeviceToHost, c->stream));
     LZX_HIP(hipStreamSynchronize(c->stream));
     LZX_TRY(lzx_comm_ipc_check(c));
-    for (int p = 0; p < c->world; ++p) memcpy(all.data() + (size_t)p * bytes, raw.data() + (size_t)p * IPC_BOARD, bytes);
+    for (int p = 0; p < c->world; ++p) {
+        BoardHead h;
+        memcpy(&h, raw.data() + (size_t)p * IPC_BOARD, sizeof h);
+        if (h.tag != head.tag || h.seq != head.seq) {
+            mark_broken(c);
+            LZX_FAIL(LZX_ERR_COMM, "peer windows: rank %d posted board message %u of operation %#x where this rank (%d) is at message %u of operation %#x: "
+                                   "the ranks are out of step", p, h.seq, h.tag, c->rank, head.seq, head.tag);
+        }
+        memcpy(all.data() + (size_t)p * bytes, raw.data() + (size_t)p * IPC_BOARD + sizeof h, bytes);
+    }
     return LZX_OK;
+}
+
+// this rank gives up on the communicator and says so in every peer's window (best effort: the peers may be gone)
+void mark_broken(lzx_ctx *c)
+{
+    lzx_ipc_state *s = c->ipc;
+    if (s->broken) return;
+    s->broken = true;
+    ErrPeers e{};
+    for (int p = 0; p < c->world; ++p) e.err[p] = &static_cast<Window *>(s->peer_win[p])->err;
+    hipLaunchKernelGGL(k_ipc_poison, dim3(1), dim3(64), 0, c->stream, e, (u32)c->world, (u32)c->rank);
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(c->stream);
 }
 
 void close_peer_bufs(lzx_ctx *c)
@@ -289,12 +372,15 @@ extern "C" int lzx_comm_ipc_export(lzx_handle c, uint8_t blob[LZX_IPC_BLOB])
     lzx_ipc_state *s = c->ipc;
     if (!s->win) {
         void *w = nullptr;
-        // fine-grained: a peer GPU's stores to the flags and mailboxes must not be shadowed by a line this GPU's L2 still holds
-        s->finegrained = hipExtMallocWithFlags(&w, sizeof(Window), hipDeviceMallocFinegrained) == hipSuccess;
-        if (!s->finegrained) {
+        // fine-grained: a peer's stores to the flags and mailboxes must not be shadowed by a line an L2 of this GPU still holds --
+        // another GPU's, or (ranks sharing one GPU) another XCD's.  Ordinary device memory is NOT a fallback (round 5, ADVICE r4:
+        // that its lines stay coherent among the eight XCD L2s of one GPU was asserted, never shown): a platform that cannot
+        // allocate or export fine-grained device memory does not get this transport.
+        if (hipExtMallocWithFlags(&w, sizeof(Window), hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
-            LZX_HIP(hipMalloc(&w, sizeof(Window)));
+            LZX_FAIL(LZX_ERR_COMM, "peer windows: this platform gives no fine-grained device memory for the flags and mailboxes");
         }
+        s->finegrained = true;
         if (hipMemset(w, 0, sizeof(Window)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
             (void)hipFree(w);
             LZX_FAIL(LZX_ERR_HIP, "peer windows: cannot clear the window");
@@ -303,27 +389,16 @@ extern "C" int lzx_comm_ipc_export(lzx_handle c, uint8_t blob[LZX_IPC_BLOB])
     }
     Blob b{};
     b.magic = IPC_MAGIC;
-    b.finegrained = s->finegrained ? 1u : 0u;
+    b.finegrained = 1u;
     b.pid = (int)getpid();
+    b.nonce = process_nonce();
     b.device = c->device;
     b.ptr = (u64)(uintptr_t)s->win;
-    hipError_t e = hipIpcGetMemHandle(&b.handle, s->win);
-    if (e != hipSuccess && s->finegrained) {
-        // the platform does not export fine-grained memory: an ordinary allocation (coherent among ranks of one GPU)
+    const hipError_t e = hipIpcGetMemHandle(&b.handle, s->win);
+    if (e != hipSuccess) {
         (void)hipGetLastError();
-        (void)hipFree(s->win);
-        s->win = nullptr;
-        s->finegrained = false;
-        void *w = nullptr;
-        LZX_HIP(hipMalloc(&w, sizeof(Window)));
-        LZX_HIP(hipMemset(w, 0, sizeof(Window)));
-        LZX_HIP(hipDeviceSynchronize());
-        s->win = w;
-        b.finegrained = 0;
-        b.ptr = (u64)(uintptr_t)w;
-        e = hipIpcGetMemHandle(&b.handle, w);
+        LZX_FAIL(LZX_ERR_COMM, "peer windows: this platform does not export fine-grained device memory to other processes (%s)", hipGetErrorString(e));
     }
-    LZX_HIP(e);
     memset(blob, 0, LZX_IPC_BLOB);
     memcpy(blob, &b, sizeof b);
     return LZX_OK;
@@ -339,21 +414,27 @@ extern "C" int lzx_comm_ipc_init(lzx_handle c, const uint8_t *blobs, int rank, i
     LZX_HIP(hipSetDevice(c->device));
     Blob mine;
     memcpy(&mine, blobs + (size_t)rank * LZX_IPC_BLOB, sizeof mine);
-    if (mine.magic != IPC_MAGIC || mine.pid != (int)getpid() || mine.ptr != (u64)(uintptr_t)s->win)
+    if (mine.magic != IPC_MAGIC || mine.pid != (int)getpid() || mine.nonce != process_nonce() || mine.ptr != (u64)(uintptr_t)s->win)
         LZX_FAIL(LZX_ERR_ARG, "lzx_comm_ipc_init: entry %d of the list is not this handle's own export", rank);
     for (int p = 0; p < world; ++p) {
         Blob b;
         memcpy(&b, blobs + (size_t)p * LZX_IPC_BLOB, sizeof b);
         if (b.magic != IPC_MAGIC) LZX_FAIL(LZX_ERR_ARG, "lzx_comm_ipc_init: entry %d is not an export", p);
         if (p == rank) { s->peer_win[p] = s->win; continue; }
-        if (b.pid == (int)getpid()) { s->peer_win[p] = (void *)(uintptr_t)b.ptr; continue; }   // a rank of this very process
+        if (!b.finegrained) LZX_FAIL(LZX_ERR_COMM, "peer windows: the window of rank %d is not fine-grained memory", p);
+        const bool same_process = b.pid == (int)getpid() && b.nonce == process_nonce();   // (a pid alone may repeat across PID namespaces)
         if (b.device != c->device) {
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, c->device, b.device) != hipSuccess || !can)
                 LZX_FAIL(LZX_ERR_COMM, "peer windows: GPU %d cannot access GPU %d of rank %d", c->device, b.device, p);
-            if (!b.finegrained)
-                LZX_FAIL(LZX_ERR_COMM, "peer windows: rank %d on GPU %d could only export ordinary memory; across GPUs the flags need fine-grained memory", p, b.device);
+            if (same_process) {   // no handle is opened for a rank of this very process: switch the peer mapping on here
+                const hipError_t pe = hipDeviceEnablePeerAccess(b.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    LZX_FAIL(LZX_ERR_COMM, "peer windows: cannot enable access from GPU %d to GPU %d of rank %d: %s", c->device, b.device, p, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
         }
+        if (same_process) { s->peer_win[p] = (void *)(uintptr_t)b.ptr; continue; }   // a rank of this very process
         void *ptr = nullptr;
         hipError_t e = hipIpcOpenMemHandle(&ptr, b.handle, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
@@ -408,10 +489,15 @@ int lzx_comm_ipc_check(lzx_ctx *c)
     LZX_HIP(hipSetDevice(c->device));
     LZX_HIP(hipMemcpy(&err, &w->err, sizeof err, hipMemcpyDeviceToHost));
     if (err) {
-        (void)hipMemset(&w->err, 0, sizeof err);
+        // fatal for the communicator (the word stays set, the state is marked, the peers are told)
+        mark_broken(c);
+        if (err & 0x80000000u)
+            LZX_FAIL(LZX_ERR_COMM, "peer windows: rank %u gave up on the communicator (a deadline expired there); this rank is %d of %d", (err & 0x7fffffffu) - 1,
+                     c->rank, c->world);
         LZX_FAIL(LZX_ERR_COMM, "peer windows: rank %u did not arrive within the deadline (LZX_IPC_TIMEOUT_MS, default 20 000); this rank is %d of %d", err - 1,
                  c->rank, c->world);
     }
+    IPC_ALIVE(c);
     return LZX_OK;
 }
 
@@ -419,7 +505,7 @@ int lzx_comm_ipc_agree(lzx_ctx *c, bool ok, bool *all_ok)
 {
     unsigned char v = ok ? 1 : 0;
     std::vector<unsigned char> all;
-    LZX_TRY(host_allgather(c, &v, 1, all));
+    LZX_TRY(host_allgather(c, TAG_AGREE, &v, 1, all));
     *all_ok = true;
     for (unsigned char a : all) *all_ok = *all_ok && a == 1;
     return LZX_OK;
@@ -434,6 +520,7 @@ int lzx_comm_ipc_publish(lzx_ctx *c, bool ok)
     PublishMsg m{};
     m.ok = ok ? 1u : 0u;
     m.pid = (int)getpid();
+    m.nonce = process_nonce();
     void *bufs[LZX_IPC_BUFS] = {c->d_xbuf, c->d_ybuf, c->d_xf32_full};
     const size_t bytes[LZX_IPC_BUFS] = {sizeof(double) * c->xlen, sizeof(double) * c->iolen, sizeof(float) * (size_t)c->world * c->xs};
     LZX_HIP(hipSetDevice(c->device));
@@ -449,7 +536,7 @@ int lzx_comm_ipc_publish(lzx_ctx *c, bool ok)
     }
     m.n_bufs = LZX_IPC_BUFS;
     std::vector<unsigned char> all;
-    LZX_TRY(host_allgather(c, &m, sizeof m, all));
+    LZX_TRY(host_allgather(c, TAG_PUBLISH, &m, sizeof m, all));
     bool all_ok = true;
     for (int p = 0; p < c->world; ++p) {
         PublishMsg q;
@@ -470,7 +557,7 @@ int lzx_comm_ipc_publish(lzx_ctx *c, bool ok)
             }
             s->buf[b].peer_bytes[p] = q.buf[b].bytes;
             if (!q.buf[b].ptr) continue;
-            if (p == c->rank || q.pid == (int)getpid()) { s->buf[b].peer[p] = (void *)(uintptr_t)q.buf[b].ptr; continue; }
+            if (p == c->rank || (q.pid == (int)getpid() && q.nonce == process_nonce())) { s->buf[b].peer[p] = (void *)(uintptr_t)q.buf[b].ptr; continue; }
             void *ptr = nullptr;
             if (hipIpcOpenMemHandle(&ptr, q.buf[b].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
                 (void)hipGetLastError();
@@ -505,6 +592,7 @@ void lzx_comm_ipc_unpublish(lzx_ctx *c)
 int lzx_comm_ipc_allreduce(lzx_ctx *c, u32 slot, u32 count, int op, const double *pa, u32 na, const double *pb, u32 nb)
 {
     if (count > 8 || (pa && count != 2)) LZX_FAIL(LZX_ERR_LIMIT, "peer windows: all-reduce of %u values", count);
+    IPC_ALIVE(c);
     lzx_ipc_state *s = c->ipc;
     Window *w = static_cast<Window *>(s->win);
     const u64 seq = ++s->mail_seq;
@@ -569,30 +657,22 @@ int lzx_comm_ipc_sparse_chunk1(lzx_ctx *c, bool peers_idle)
     return queue_put(c, true, a);
 }
 
-// every rank's [send counts | receive counts] on the board: all pairs checked by all ranks (the same verdict everywhere),
-// and this rank learns where its piece starts inside every peer's packed chunk 1
+// every rank's [send counts | receive counts | content hashes] on the board: all pairs checked by all ranks (the same verdict
+// everywhere), and this rank learns where its piece starts inside every peer's packed chunk 1
 int lzx_comm_ipc_check_sparse(lzx_ctx *c)
 {
     const u32 world = (u32)c->world;
-    std::vector<u32> mine(2 * (size_t)world);
-    for (u32 p = 0; p < world; ++p) {
-        mine[p] = c->sx_send_off[p + 1] - c->sx_send_off[p];
-        mine[world + p] = c->sx_recv_off[p + 1] - c->sx_recv_off[p];
-    }
+    std::vector<u32> mine;
+    lzx_sx_check_message(c, mine);
     std::vector<unsigned char> raw;
-    LZX_TRY(host_allgather(c, mine.data(), sizeof(u32) * mine.size(), raw));
-    std::vector<u32> all(2 * (size_t)world * world);
+    LZX_TRY(host_allgather(c, TAG_SPARSE, mine.data(), sizeof(u32) * mine.size(), raw));
+    std::vector<u32> all(mine.size() * world);
     memcpy(all.data(), raw.data(), sizeof(u32) * all.size());
-    for (u32 p = 0; p < world; ++p)
-        for (u32 q = 0; q < world; ++q) {
-            const u32 sends = all[(size_t)p * 2 * world + q], expects = all[(size_t)q * 2 * world + world + p];
-            if (sends != expects)
-                LZX_FAIL(LZX_ERR_STATE, "sparse exchange: rank %u packs %u entries for rank %u, which expects %u", p, sends, q, expects);
-        }
+    LZX_TRY(lzx_sx_check_pairs(all, world));
     c->ipc->sx_dst_off.assign(world, 0);
     for (u32 p = 0; p < world; ++p) {
         u64 off = 0;
-        for (int r = 0; r < c->rank; ++r) off += all[(size_t)p * 2 * world + world + r];   // what p receives from the ranks before this one
+        for (int r = 0; r < c->rank; ++r) off += all[(size_t)p * mine.size() + world + r];   // what p receives from the ranks before this one
         c->ipc->sx_dst_off[p] = off;
     }
     return LZX_OK;

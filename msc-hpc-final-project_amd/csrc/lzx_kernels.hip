@@ -231,6 +231,14 @@ __global__ void k_permute_in(const double *io, const u32 *gidx, double *full, do
     if (o < n) full[gidx[o]] = io[o] / div;
 }
 
+// a constant start vector is made where it is used (lzx_api.hip: scan_start_vector) instead of crossing PCIe
+__global__ void k_fill(double *out, double value, u64 n)
+{
+    const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) *reinterpret_cast<double2 *>(out + i) = make_double2(value, value);
+    else if (i < n) out[i] = value;
+}
+
 // hand-over layout [world][n_loc_pad] -> exchange layout [world][xs]: the first xs entries of every slice
 __global__ void k_relayout(const double *io_layout, double *x, u32 world, u32 n_loc_pad, u32 xs, u32 xs0)
 {
@@ -731,6 +739,14 @@ int lzx_launch_permute_in(lzx_ctx *c, const double *io, double *full, double div
     if (c->n == 0) return LZX_OK;
     const u32 g = (u32)((c->n + 255) / 256);
     hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, c->stream, io, c->d_gidx_of_old, full, div, c->n);
+    LZX_HIP(hipGetLastError());
+    return LZX_OK;
+}
+
+int lzx_launch_fill(lzx_ctx *c, double *out, double value, u64 count)
+{
+    if (count == 0) return LZX_OK;
+    hipLaunchKernelGGL(k_fill, dim3((u32)((count / 2 + 256) / 256)), dim3(256), 0, c->stream, out, value, count);
     LZX_HIP(hipGetLastError());
     return LZX_OK;
 }

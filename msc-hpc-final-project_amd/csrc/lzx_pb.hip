@@ -1048,18 +1048,19 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
 // tables with d_pb_val in five fresh allocations read 1.05 / 1.22 / 1.23 / 1.23 / 1.23 ms on the Erdos-Renyi benchmark graph
 // and 0.520-0.531 ms on the R-MAT one, while moving any other array changes nothing (debug library, LZX_RELOC_SHOP;
 // profiles/r4_placement.txt) -- the "process states" of rounds 2-4.  User space cannot choose physical memory, but it can
-// ask again: the buffer is allocated up to `placement_trials` more times (earlier candidates stay allocated meanwhile, so
-// every one is different memory), the SpMV is timed with each (3 runs of x = 0: its time does not depend on the values)
-// and the fastest is kept.  The buffer is scratch that only needs its zero padding, so a trial costs an allocation, a
+// ask again: the buffer is allocated up to `placement_trials` more times (the best so far and the last loser stay allocated
+// meanwhile, so every candidate is different memory), the SpMV is timed with each (3 runs of x = 0: its time does not depend on
+// the values) and the fastest is kept.  The buffer is scratch that only needs its zero padding, so a trial costs an allocation, a
 // clear and three SpMVs.  Results are bit-identical whichever candidate wins.
 int lzx_pb_place_values(lzx_ctx *c)
 {
     c->place_tried = c->place_kept = 0;
     const size_t bytes = sizeof(double) * (c->pb_values + 8);
-    // default: seven more candidates, fewer where they would hold more than 16 GB among them (the driver clears what it hands out:
-    // a 10 GB allocation takes most of a second)
-    const u32 trials = c->place_opt >= 0 ? (u32)std::min<int64_t>(c->place_opt, 7)
-                                         : (u32)std::min<u64>(7, std::max<u64>(1, (16ull << 30) / std::max<size_t>(bytes, 1)));
+    // default: two more candidates (round 5, ADVICE r4: a library that may sit inside a host framework does not hold eight copies
+    // of a stream at its hand-over by default; bench.py asks for seven and reports what they read); never more than 16 GB among
+    // the candidates tried (the driver clears what it hands out: a 10 GB allocation takes most of a second)
+    const u32 trials = (u32)std::min<u64>(c->place_opt >= 0 ? (u64)std::min<int64_t>(c->place_opt, 7) : 2ull,
+                                          c->place_opt >= 0 ? 7ull : std::max<u64>(1, (16ull << 30) / std::max<size_t>(bytes, 1)));
     if (!c->pb || !c->d_pb_val || trials == 0 || bytes < LZX_PB_NT_BYTES) return LZX_OK;   // a stream the caches hold: nothing to choose
     LZX_HIP(hipSetDevice(c->device));
     const bool multi = lzx_exchanges(c);
@@ -1077,8 +1078,10 @@ int lzx_pb_place_values(lzx_ctx *c)
         }
         return LZX_OK;
     };
-    double *cand[8] = {c->d_pb_val};
-    u32 n_cand = 1, kept = 0;
+    // At most three candidates are alive at any time: the best so far, the one being timed, and the last loser -- which is freed
+    // only AFTER the next allocation, so that the driver cannot hand the same memory out again as a "new" candidate.
+    double *best_buf = c->d_pb_val, *loser = nullptr;
+    u32 kept = 0;
     int rc = time_spmv(&c->place_ms[0]);
     for (u32 t = 1; rc == LZX_OK && t <= trials; ++t) {
         size_t free_b = 0, total_b = 0;
@@ -1087,20 +1090,25 @@ int lzx_pb_place_values(lzx_ctx *c)
         // (other memory types are no way out: hipDeviceMallocContiguous and hipDeviceMallocUncached candidates read 1.76 ms on the
         //  Erdos-Renyi graph and 0.70 ms on the R-MAT one against 1.05-1.24 / 0.53-0.55; fine-grained ones draw from the same lottery)
         if (hipMalloc(reinterpret_cast<void **>(&fresh), bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        cand[n_cand++] = fresh;
-        if (hipMemsetAsync(fresh, 0, bytes, c->stream) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (loser) { (void)hipFree(loser); loser = nullptr; }
+        if (hipMemsetAsync(fresh, 0, bytes, c->stream) != hipSuccess) { (void)hipGetLastError(); loser = fresh; break; }
         c->d_pb_val = fresh;
         rc = time_spmv(&c->place_ms[t]);
-        if (rc != LZX_OK) break;
-        if (c->place_ms[t] < c->place_ms[kept]) kept = t;
+        if (rc != LZX_OK) { loser = fresh; break; }
         c->place_tried = t + 1;
+        if (c->place_ms[t] < c->place_ms[kept]) {
+            kept = t;
+            loser = best_buf;
+            best_buf = fresh;
+        } else {
+            loser = fresh;
+        }
     }
     if (c->place_tried == 0) c->place_tried = 1;
     (void)hipStreamSynchronize(c->stream);
-    c->d_pb_val = cand[kept];
+    if (loser) (void)hipFree(loser);
+    c->d_pb_val = best_buf;
     c->place_kept = kept;
-    for (u32 t = 0; t < n_cand; ++t)
-        if (t != kept) (void)hipFree(cand[t]);
     // the SpMV wrote v and the partials: leave them as the hand-over does
     LZX_HIP(hipMemsetAsync(c->d_v, 0, sizeof(double) * c->ldq, c->stream));
     LZX_HIP(hipMemsetAsync(c->d_pb_val, 0, bytes, c->stream));

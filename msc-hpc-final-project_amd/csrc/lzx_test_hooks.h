@@ -9,7 +9,9 @@
 // "pb_carry_scan" (reduced steps: a row that spans lanes summed by the fixed-order cross-lane scan 1 / through LDS carry slots 0),
 // "isolated_rows" (0: rows without an edge updated elementwise instead of as one scalar recurrence), "unnormalised_basis" (0: the
 // resident basis holds q_j instead of u_j), "fuse_staged" (0: staged-columns kernel in a launch of its own; 1: behind the
-// scatter units of the shared launch instead of ahead of them).
+// scatter units of the shared launch instead of ahead of them), "start_vector_scan" (0: lzx_lanczos_prepare_f64 always uploads x0 and
+// sums its squares in one serial chain; default: one look at x0 first -- a constant vector is filled on the device, a sum that is
+// exact in any order is formed by several threads).
 #pragma once
 #include <stdint.h>
 #include "lzx.h"
@@ -19,7 +21,8 @@ extern "C"
 int lzx_test_set_shape(lzx_handle h, const char *name, int64_t value);
 // what shape the tables of the handle's graph took: "gather_items_dealt" / "gather_items_drawn" (static lists / dynamic tail of
 // the gather pass), "gather_workgroups", "placement_tried" / "placement_kept" / "placement_us_<i>" (option placement_trials: candidates of
-// the value stream timed at the last hand-over, the one kept, the SpMV time of candidate i in microseconds"
+// the value stream timed at the last hand-over, the one kept, the SpMV time of candidate i in microseconds), "start_vector_was_constant"
+// (the last prepared x0 was filled on the device instead of uploaded)
 #ifdef __cplusplus
 extern "C"
 #endif

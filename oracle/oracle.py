@@ -162,6 +162,38 @@ def lanczos(row_offset, col_idx, k: int, x, want_q: bool = True, q_colmajor: boo
     return alpha, beta[:k - 1], Q, xn.value
 
 
+_OMP = None
+
+
+def lanczos_omp(row_offset, col_idx, k: int, x, threads: int = 0):
+    """The all-core companion of `lanczos` (lanczos_oracle_omp.c: the same loop, OpenMP over rows and elements; inner products
+    are OpenMP reductions, so alpha / beta carry another rounding).  A TIMING baseline (bench.py, kind "port-omp"), not a parity
+    oracle.  Returns (alpha[k], beta[k-1], x_norm, threads used).  `threads` > 0 sets OMP_NUM_THREADS before the library is
+    first loaded (the OpenMP runtime reads it once)."""
+    global _OMP
+    if _OMP is None:
+        if threads > 0:
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+        so = os.path.join(_HERE, "liboracle_omp.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        L.orc_lanczos_omp.argtypes = [ctypes.c_uint64, _u64p, _u32p, ctypes.c_uint32, _f64p, _f64p, _f64p, _f64p]
+        L.orc_lanczos_omp.restype = ctypes.c_int
+        L.orc_omp_threads.restype = ctypes.c_int
+        _OMP = L
+    n = len(row_offset) - 1
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    alpha = np.zeros(k)
+    beta = np.zeros(max(k - 1, 1))
+    xn = ctypes.c_double(0.0)
+    rc = _OMP.orc_lanczos_omp(n, _p(row_offset, _u64p), _p(col_idx, _u32p), k, _p(x, _f64p), _p(alpha, _f64p), _p(beta, _f64p),
+                              ctypes.byref(xn))
+    if rc != 0:
+        raise MemoryError("orc_lanczos_omp")
+    return alpha, beta[:k - 1], xn.value, int(_OMP.orc_omp_threads())
+
+
 def lanczos_arnoldi(row_offset, col_idx, k: int, x, every: int = 2):
     """serial/lib/lanczos.cc:58-132 (decompose_with_arnoldi; the reference's every = 2).  Returns (alpha[k],
     beta[k-1], Q (k, n), x_norm)."""

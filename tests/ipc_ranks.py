@@ -136,6 +136,22 @@ if rank == 0:
         assert "did not arrive" in str(exc) and waited < 10.0, (str(exc), waited)
         print(f"[ipc_ranks] world={world}: a collective entered by rank 0 alone failed after {waited:.2f} s: {str(exc)[-110:]}", flush=True)
 dist.barrier()
+# ... and it is FATAL for the communicator (round 5): the ranks' sequence numbers no longer describe the same operations,
+# so rank 0 refuses every later collective at once, and the peers -- whose windows it poisoned -- fail fast with "gave up", not
+# after a deadline of their own and never with another operation's mailbox values
+t = time.time()
+try:
+    eng.allreduce_latency(4)
+    raise AssertionError("a collective on a broken communicator returned")
+except pkg.LzxError as exc:
+    assert ("is broken" in str(exc)) if rank == 0 else ("gave up" in str(exc)), (rank, str(exc))
+    assert time.time() - t < 10.0
+try:
+    eng.allreduce_latency(4)
+    raise AssertionError("a collective on a broken communicator returned")
+except pkg.LzxError as exc:
+    assert "is broken" in str(exc), (rank, str(exc))
+dist.barrier()
 eng.close()
 dist.barrier()
 if rank == 0:

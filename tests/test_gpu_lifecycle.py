@@ -180,3 +180,37 @@ def test_placement_trials_change_no_bit(pkg):
     small.gen_er(200_000, 1_000_000, 3)
     assert small.shape("placement_tried") == 0
     small.close()
+
+
+def test_start_vector_hand_over_fast_paths(pkg, oracle):
+    """Round 5: lzx_lanczos_prepare_f64 looks at x0 once.  A constant vector -- the reference's own start
+    vector is ones, parallel-final/main.cu:79 -- is filled on the device instead of crossing PCIe; a sum of squares that is exact
+    in any order (integer entries) is formed by several host threads instead of serial/'s one dependent chain
+    (serial/lib/lanczos.cc:155-161).  Neither may change a bit: compared with the plain hand-over (test shape
+    start_vector_scan = 0) and with the oracle's norm."""
+    O = oracle
+    rp, ci = O.gen_rmat(17, 120000, 1500000, 3)
+    n = len(rp) - 1
+    rng = np.random.default_rng(5)
+    cases = {
+        "ones": (np.ones(n), True),
+        "constant 0.3 (squares not exact)": (np.full(n, 0.3), True),
+        "small integers": (rng.integers(-9, 10, n).astype(np.float64), False),
+        "general": (rng.random(n), False),
+        "one entry differs, at the end": (np.concatenate([np.ones(n - 1), [2.0]]), False),
+        "too large for exact squares": (np.full(n, 2.0 ** 27), True),
+    }
+    for mode in (dict(propagation_blocking=0), dict(propagation_blocking=1, hub_entries=512)):
+        fast = pkg.Engine(0, **mode)
+        plain = pkg.Engine(0, start_vector_scan=0, **mode)
+        fast.set_graph_csr(rp, ci)
+        plain.set_graph_csr(rp, ci)
+        for name, (x0, const) in cases.items():
+            a1, b1, Q1, xn1, _ = fast.lanczos(x0, 8)
+            assert fast.shape("start_vector_was_constant") == int(const), name
+            a0, b0, Q0, xn0, _ = plain.lanczos(x0, 8)
+            assert plain.shape("start_vector_was_constant") == 0
+            assert xn1 == xn0 == O.lanczos(rp, ci, 1, x0, want_q=False)[3], name   # serial/'s left-to-right norm, to the bit
+            assert np.array_equal(a1, a0) and np.array_equal(b1, b0) and np.array_equal(Q1, Q0), (name, mode)
+        fast.close()
+        plain.close()

@@ -131,3 +131,62 @@ def test_sharded_edge_list_errors_and_empty(pkg):
     ref[0] = 5.0; ref[5] = 0.0 + 5.0; ref[63] = 1.0; ref[1] = 63.0
     assert np.array_equal(y, ref)
     eng.close()
+
+
+def test_sharded_hand_over_catches_an_asymmetric_pattern(pkg, oracle):
+    """with the sharded hand-over a rank derives what it SENDS to each peer from its own rows through the matrix's
+    symmetry, and until round 5 the hand-over compared only how MANY entries travel between every pair of ranks.  A caller's CSR
+    that is not symmetric can keep every count and change the members: row i (rank A) references j' instead of j, both owned by
+    rank B -- A still expects one value from B, B still packs one (x_j: its row j holds i), and A's product silently uses x_j for
+    x_j'.  Now the lists are compared by content too (one order-dependent hash per pair): the sharded hand-over of such a CSR is
+    an error at the group's first operation; the whole-graph hand-over, which sees every row, multiplies it correctly."""
+    O = oracle
+    n, world = 60000, 3
+    rp, ci = O.gen_er(n, 150000, 17)
+    opts = dict(propagation_blocking=1, hub_entries=512, overlap_exchange=1, sparse_exchange=1)
+    grp = pkg.LocalGroup([0] * world, sharded_ingest=1, **opts)
+    grp.set_graph_csr(rp, ci)
+    assert grp.engines[0].info()["exchange_chunk0"] > 0          # two chunks, the second one sparse
+    owner = np.empty(n, dtype=np.int64)
+    for r, e in enumerate(grp.engines):
+        owner[e.rank_row_sums()[1]] = r
+    x = np.random.default_rng(2).random(n)
+    assert np.allclose(grp.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+    grp.close()
+    # a row i of rank 0 with a column j of rank 1 that no other row of rank 0 references, and a j' of rank 1 that no row of rank 0
+    # references at all; both of low degree (the sparse second chunk, not the dense first one)
+    deg = np.diff(rp.astype(np.int64))
+    rows = np.repeat(np.arange(n), deg)
+    ref0 = np.bincount(ci[owner[rows] == 0], minlength=n)        # how many rows of rank 0 reference each column
+    found = None
+    for i in np.flatnonzero((owner == 0) & (deg >= 2)):
+        for j in ci[rp[i]:rp[i + 1]]:
+            if owner[j] == 1 and ref0[j] == 1 and deg[j] <= 4:
+                cand = np.flatnonzero((owner == 1) & (ref0 == 0) & (deg > 0) & (deg <= 4))
+                cand = cand[~np.isin(cand, ci[rp[i]:rp[i + 1]])]
+                if len(cand):
+                    found = (int(i), int(j), int(cand[0]))
+                    break
+        if found:
+            break
+    assert found, "the test graph has no such triple"
+    i, j, j2 = found
+    bad = ci.copy()
+    row = bad[rp[i]:rp[i + 1]]
+    row[row == j] = j2
+    row.sort()                                                   # (a view: the row stays ascending, every degree stays what it was)
+    y_ref = O.spmv(rp, bad, x)
+    assert not np.array_equal(y_ref, O.spmv(rp, ci, x))
+    whole = pkg.LocalGroup([0] * world, **opts)                  # every rank sees every row: the lists are right by themselves
+    whole.set_graph_csr(rp, bad)
+    assert np.allclose(whole.spmv(x), y_ref, rtol=1e-13, atol=0)
+    whole.close()
+    part = pkg.LocalGroup([0] * world, sharded_ingest=1, **opts)
+    part.set_graph_csr(rp, bad)
+    with pytest.raises(pkg.LzxError, match="OTHER ones"):
+        part.spmv(x)
+    with pytest.raises(pkg.LzxError):
+        part.lanczos(np.ones(n), 5)
+    part.set_graph_csr(rp, ci)                                   # the handles are still good
+    assert np.allclose(part.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+    part.close()

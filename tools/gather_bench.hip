@@ -160,6 +160,32 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "sym")) {
+        // Round 5, VERDICT r4 item 1 (A = A^T): a scatter unit that also adds the transposed contribution y_B[j] += x_i needs x of
+        // the ROWS that stream past it -- per (row, column band) pair one x_i, the unit's rows being a sorted, sparse subset of the
+        // vertex order.  tools/symmetric_stats.py counts them on C3: 41.7 M fetches per SpMV touching 13.2 M lines (3.16 doubles per
+        // 128-byte line; the M-L block 3.14, M-M 12.5, L-L 1.24).  What do such fetches cost?  x = the 5.9 M vertices with an edge.
+        const uint32_t table = 5903948u;
+        const double per_line[] = {1.24, 3.14, 6.0, 12.5, 16.0};
+        for (double d : per_line) {
+            const uint32_t W = (uint32_t)(d * table / 16.0) & ~3u;   // a window = one unit's rows: W ascending fetches spread over all of x
+            fill_idx_sorted<<<(unsigned)((count + 255) / 256), 256>>>(idx, count, table, W);
+            CHECK(hipDeviceSynchronize());
+            const uint64_t n_windows = count / W;
+            float bb = 1e30f;
+            for (int r = 0; r < 3; ++r) {
+                CHECK(hipEventRecord(a));
+                gather_bands_k<<<256, 1024>>>(idx, n_windows, W, tab, out);
+                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                float ms; CHECK(hipEventElapsedTime(&ms, a, b)); if (ms < bb) bb = ms;
+            }
+            const double done = (double)n_windows * W, rate = done / bb / 1e6;   // G fetches / s
+            printf("x = 47 MB, %5.2f needed doubles per 128-byte line, one workgroup per unit, 256 side by side: %7.1f G fetches/s = %5.2f TB/s of lines touched"
+                   " -> the 41.7 M x_i of one C3 SpMV take %.3f ms (4-byte index stream included)\n", d, rate, rate * 1e9 / d * 128.0 / 1e12, 41.7e6 / (rate * 1e9) * 1e3);
+            fflush(stdout);
+        }
+        return 0;
+    }
     const uint64_t tables[] = {4096, 1ull << 17, 1ull << 19, 1ull << 20, 1ull << 22, 10ull << 20, 1ull << 25, 1ull << 27, 1ull << 28};
     for (int skew = 0; skew < 2; ++skew)
         for (uint64_t t : tables) {
