@@ -412,21 +412,36 @@ static X0Scan scan_start_vector(const double *x0, u64 n)
     const double first = x0[0];
     auto work = [&](u32 t) {
         const u64 a = n * t / T, b = n * (t + 1) / T;
-        double acc = 0.0;
+        // four accumulators: used only when every square is an exact integer, and then any order gives the same bits -- so the
+        // inner loop is free of the one dependent chain (and of libm calls: an integer is what survives the round trip through
+        // int64, magnitudes <= 2^26 checked first)
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
         bool cst = true, itg = true;
         for (u64 i0 = a; i0 < b; i0 += 4096) {
             const u64 i1 = std::min<u64>(b, i0 + 4096);
-            for (u64 i = i0; i < i1; ++i) {
+            u64 i = i0;
+            for (; i + 4 <= i1; i += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double v = x0[i + u];
+                    cst &= v == first;
+                    const bool small = std::fabs(v) <= 67108864.0;   // (NaN fails)
+                    itg &= small && (double)(int64_t)(small ? v : 0.0) == v;
+                    acc[u] += v * v;
+                }
+            }
+            for (; i < i1; ++i) {
                 const double v = x0[i];
                 cst &= v == first;
-                itg &= std::fabs(v) <= 67108864.0 && v == std::nearbyint(v);   // (NaN fails both)
-                acc += v * v;
+                const bool small = std::fabs(v) <= 67108864.0;
+                itg &= small && (double)(int64_t)(small ? v : 0.0) == v;
+                acc[0] += v * v;
             }
             if (!cst) all_const.store(false, std::memory_order_relaxed);
             if (!itg) all_int.store(false, std::memory_order_relaxed);
             if (!all_const.load(std::memory_order_relaxed) && !all_int.load(std::memory_order_relaxed)) return;
         }
-        part[t] = acc;
+        part[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     };
     {
         std::vector<std::thread> th;
@@ -455,6 +470,16 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     const u64 n = c0->n;
     const bool multi = lzx_exchanges(c0);
     const bool lazy = loop_is_lazy(c0);
+    // LZX_TRACE_PREPARE=1: where this call's milliseconds go (stderr), for tools/handover_probe.py
+    static const bool trace = getenv("LZX_TRACE_PREPARE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        for (lzx_ctx *c : cs) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[lzx prepare] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     for (lzx_ctx *c : cs) {
         if (c->reorth_opt != c0->reorth_opt || c->qf32_opt != c0->qf32_opt) LZX_FAIL(LZX_ERR_STATE, "handles carry different loop options");
         if (c->qf32_opt > 0 && (!lazy || c->basis_u_opt == 0))
@@ -476,6 +501,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     const bool want_qf32 = c0->qf32_opt > 0;
     for (lzx_ctx *c : cs) LZX_TRY(ensure_capacity(c, k, want_qf32));
     for (lzx_ctx *c : cs) c->qf32 = want_qf32;
+    lap("checks, basis sized");
 
     // ||x0||: left-to-right sum of squares on the host, then sqrt (serial/lib/lanczos.cc:155-161) -- one dependent chain of
     // n additions (7 ms at n = 10 M), on a helper thread while this one sizes the basis, clears it and uploads x0 (a pageable
@@ -483,6 +509,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
     // (round 5) unless one look at x0 shows that the sum is exact in any order -- then it was formed by scan_start_vector's
     // threads -- and, for a constant vector, that there is nothing to upload
     const X0Scan scan = c0->x0_scan_opt != 0 ? scan_start_vector(x0, n) : X0Scan{};
+    lap("look at x0");
     double ss = scan.sum_sq;
     struct Joiner {
         std::thread t;
@@ -510,7 +537,9 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
         else LZX_HIP(hipMemcpyAsync(c->d_io, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
         c->x0_was_constant = scan.constant;
     }
+    lap("clears + x0 on the device");
     if (norm_thread.t.joinable()) norm_thread.t.join();
+    lap("serial norm chain (if any)");
     const double x_norm = std::sqrt(ss);
     if (x_norm_out) *x_norm_out = x_norm;
     for (lzx_ctx *c : cs) {
@@ -545,6 +574,7 @@ static int lanczos_prepare(std::vector<lzx_ctx *> &cs, const double *x0, u32 k, 
             if (c->iso_on) LZX_TRY(lzx_launch_iso_prepare(c, k));
         }
     }
+    lap("q_0, rows without an edge");
     LZX_TRY(sync_all(cs));
     for (lzx_ctx *c : cs) c->k_prep = k;
     return LZX_OK;

@@ -240,7 +240,7 @@ struct lzx_ctx {
     u32 *d_pb_items = nullptr;         // [pb_n_items][4] row band, begin, end (gather order), slot or ~0
     u32 *d_pb_multi = nullptr;         // [pb_n_multi][4] row, first slot, items, slot stride: rows of bands cut into several items
     double *d_pb_part = nullptr;       // item totals of those rows
-    uint8_t *d_pb_long_multi = nullptr; // [n_long64] 1: the split row is also listed in d_pb_multi
+    uint8_t *d_pb_long_multi = nullptr; // [n_long64] who closes the split row: 0 the gather fold, 1 its multi thread (d_pb_multi), 2 k_pb_finish's split-row thread
     int64_t pb_stamps_opt = -1;
     unsigned long long *d_pb_gstamps = nullptr;  // [pb_gather_grid][8] debug library, option pb_stamps: the product gather pass's sections
     int64_t tie_sort_opt = -1;         // blocked mode: ties of the degree ranking broken by staged-column count (debug knob; 0 = by id)

@@ -674,8 +674,28 @@ template <bool STAMP, bool NT, bool NOSLOT = false>
 __global__ void __launch_bounds__(LZX_PB_GATHER_BLOCK, 4)   // four wavefronts per SIMD = two workgroups per CU: at most 128 VGPRs (the stamped build took 129 and ran one per CU)
 k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *item_dot, const u32 *band_row0, const u32 *band_rep,
             const u32 *band_beg, const uint16_t *lslot, const double *val, double *v, const double *__restrict__ q_loc, double *part,
-            double *partials, unsigned long long *stamps, const u32 probe_l2g)
+            double *partials, unsigned long long *stamps, const u32 probe_l2g, const u32 *item_first, const double *long_partial,
+            const uint8_t *long_mode, const u32 n_long)
 {
+    // Round 5: the SPLIT ROWS of the staged-columns kernel (local rows [0, n_long): their item totals, long_partial) are closed
+    // HERE, by the fold that writes the row anyway, when the row's band is a single gather item (long_mode 0) -- on graphs without
+    // multi-item bands (the 1 M-vertex benchmark graph) k_pb_finish then has nothing left to do and is not launched: three launches
+    // per SpMV become two.  Same operands in the same order as k_pb_finish added them: v = (v + y) + s -- in a short loop BEHIND the
+    // fold (inside it the extra live values cost the 128-VGPR build six spills).
+    // first..first + stride * m: the rows THIS thread has just folded (it re-reads its own stores); almost every band lies beyond
+    // n_long, where the wave-uniform test ends the matter
+    auto close_split_rows = [&](u32 row0, u32 rows, u32 first, u32 stride, double &dot) {
+        if (row0 >= n_long) return;
+        const u32 lim = min(rows, n_long - row0);
+        for (u32 j = first; j < lim; j += stride) {
+            const u32 row = row0 + j;
+            if (long_mode[row] != 0) continue;
+            double sl = 0.0;
+            for (u32 it = item_first[row]; it < item_first[row + 1]; ++it) sl += long_partial[it];
+            v[row] += sl;
+            dot += sl * q_loc[row];
+        }
+    };
     unsigned long long t_start = 0, t_mark = 0, t_zero = 0, t_stream = 0, t_bar = 0, t_fold = 0, n_vals = 0;
     u32 n_it = 0;
 #define GSTAMP(acc) do { if (STAMP) { const unsigned long long t_ = wall_clock64(); acc += t_ - t_mark; t_mark = t_; } } while (0)
@@ -866,6 +886,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                         }
                     }
                 }
+                close_split_rows(row0, rows, lane, 64u, dot);
                 GSTAMP(t_fold);
             }
             continue;
@@ -893,8 +914,15 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                 double t = 0.0;
                 for (u32 w = 0; w < WAVES; ++w) t += wsum[w];
                 if (item_w == 0xffffffffu) {
-                    v[row0] += t;
+                    double vr = v[row0] + t;
                     dot += t * q_loc[row0];
+                    if (row0 < n_long && long_mode[row0] == 0) {
+                        double sl = 0.0;
+                        for (u32 it = item_first[row0]; it < item_first[row0 + 1]; ++it) sl += long_partial[it];
+                        vr += sl;
+                        dot += sl * q_loc[row0];
+                    }
+                    v[row0] = vr;
                 } else {
                     part[item_w] = t;
                 }
@@ -960,6 +988,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     }
                 }
             }
+            close_split_rows(row0, rows, tid, LZX_PB_GATHER_BLOCK, dot);
         } else {
             for (u32 j = tid; j < rows; j += LZX_PB_GATHER_BLOCK) {
                 double y = 0.0;
@@ -1005,10 +1034,12 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
 
 // v[row] += totals that were left for it, in their fixed order; alpha partials for those rows.  Threads [0, n_multi):
 // rows of bands cut into several gather items (their per-item totals); threads behind them: the split rows of the
-// staged-column kernel (their item totals, k_long_finish's job in plain mode).
+// staged-column kernel (their item totals, k_long_finish's job in plain mode) that no gather item covers (long_mode 2: a row
+// without a blocked entry; mode 0 rows were closed by the gather pass's fold, mode 1 rows by their multi thread here).
+// Launched only when there is such work (pb_prepare_impl: pb_finish_grid).
 __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32 n_multi, const double *part,
-            const u32 *item_first, const double *long_partial, const uint8_t *long_is_multi, u32 n_long, double *v,
+            const u32 *item_first, const double *long_partial, const uint8_t *long_mode, u32 n_long, double *v,
             const double *q_loc, double *partials, const double *item_dot, u32 n_item_dot)
 {
     __shared__ double sh[4];
@@ -1026,7 +1057,7 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
             for (u32 it = item_first[row]; it < item_first[row + 1]; ++it) s += long_partial[it];
         v[row] += s;
         dot = s * q_loc[row];
-    } else if (t - n_multi < n_long && !long_is_multi[t - n_multi]) {
+    } else if (t - n_multi < n_long && long_mode[t - n_multi] == 2) {
         const u32 r = t - n_multi;
         double s = 0.0;
         for (u32 it = item_first[r]; it < item_first[r + 1]; ++it) s += long_partial[it];
@@ -1749,10 +1780,17 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         LZX_HIP(hipMemsetAsync(c->d_pb_gstamps, 0, sizeof(unsigned long long) * 8 * c->pb_gather_grid, st));
     }
 #endif
-    {   // split rows (the first n_long64 local rows) that are also rows of a multi-item band
-        std::vector<uint8_t> flag((size_t)c->n_long64 + 1, 0);
+    u32 n_uncovered = 0;
+    {   // split rows (the first n_long64 local rows): who closes them?  0 = the gather pass's fold (the row's band is one gather
+        // item), 1 = the row's multi thread of k_pb_finish (its band was cut into several items), 2 = k_pb_finish's split-row
+        // thread (no gather item covers the row: it has no blocked entry)
+        std::vector<uint8_t> flag((size_t)c->n_long64 + 1, 2);
+        for (u32 R = 0; R < nr; ++R)
+            if (rstart[R] != rstart[R + 1])
+                for (u32 r = row0[R]; r < std::min<u32>(row0[R + 1], c->n_long64); ++r) flag[r] = 0;
         for (size_t i = 0; i < multi.size(); i += 4)
             if (multi[i] < c->n_long64) flag[multi[i]] = 1;
+        for (u32 r = 0; r < c->n_long64; ++r) n_uncovered += flag[r] == 2 ? 1 : 0;
         LZX_TRY(pb_alloc(&c->d_pb_long_multi, flag.size()));
         LZX_HIP(hipMemcpyAsync(c->d_pb_long_multi, flag.data(), flag.size(), hipMemcpyHostToDevice, st));
         LZX_HIP(hipStreamSynchronize(st));
@@ -1781,7 +1819,8 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     c->pb_nr = nr;
     constexpr u32 waves_per_wg = LZX_PB_GATHER_BLOCK / 64;
     (void)waves_per_wg;
-    c->pb_finish_grid = (c->pb_n_multi + c->n_long64 + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;   // + the split rows of k_spmv
+    // k_pb_finish: the rows of multi-item bands, then (only when some split row is covered by no gather item) a thread per split row
+    c->pb_finish_grid = (c->pb_n_multi + (n_uncovered ? c->n_long64 : 0u) + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
     if (c->pb_n_dyn) c->pb_finish_grid = std::max<u32>(c->pb_finish_grid, (c->pb_n_dyn + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK);   // + the drawn items' alpha partials
     return LZX_OK;
 }
@@ -1898,7 +1937,8 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         LZX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(kern, dim3(c->pb_gather_grid), dim3(LZX_PB_GATHER_BLOCK), lds2, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_items), c->pb_n_static, c->pb_n_dyn, c->d_pb_gcounter, c->d_pb_item_dot, c->d_pb_row0,
-                           c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, stamps, probe_l2g);
+                           c->d_pb_rep, c->d_pb_beg, c->d_pb_lrow, c->d_pb_val, v, q_loc, c->d_pb_part, partials, stamps, probe_l2g,
+                           c->d_item_first, c->d_long_partial, c->d_pb_long_multi, c->n_long64);
         return LZX_OK;
     };
     bool gathered = false;

@@ -11,6 +11,8 @@ So: err(engine vs referee) <= 1.5 x err(oracle vs referee) at k = 50, and <= 1e-
 import numpy as np
 import pytest
 
+from bench import C2_DRAWS, C3_DRAWS, ER_DRAWS   # BASELINE's configurations at their named edge counts (bench.py: WORKLOADS)
+
 pytestmark = pytest.mark.gpu
 
 CAPS = (0.0, 40.0)          # referee_expm's caps: 0 -> e^(A - theta_max) x (shift_weights(cap=None)), 40 -> shift_weights(cap=40)
@@ -98,7 +100,7 @@ def test_c2_k50_against_referee(pkg, oracle):
     O = oracle
     n, k = 1 << 20, 50
     eng = pkg.Engine(0)
-    eng.gen_rmat(20, n, 20_000_000, 1234)          # BASELINE C2
+    eng.gen_rmat(20, n, C2_DRAWS, 1234)          # BASELINE C2
     rp, ci = eng.get_graph_csr()
     rows = _protocol(O, eng, rp, ci, n, k, "C2", small_ks=(8, 10, 20), want_q=True)
     # the 1e-10 criterion was really exercised somewhere (k = 8 and 10, where serial/ achieves it)
@@ -112,7 +114,7 @@ def test_c3_k50_against_referee(pkg, oracle):
     O = oracle
     n, k = 10_000_000, 50
     eng = pkg.Engine(0)
-    eng.gen_rmat(24, n, 200_000_000, 1234)         # BASELINE C3 / C4 graph
+    eng.gen_rmat(24, n, C3_DRAWS, 1234)         # BASELINE C3 / C4 graph
     rp, ci = eng.get_graph_csr()
     _protocol(O, eng, rp, ci, n, k, "C3", small_ks=(8,), want_q=False)
     eng.close()
@@ -171,7 +173,7 @@ def test_reorthogonalised_variant(pkg, oracle):
     # C2, k = 50
     n, k = 1 << 20, 50
     eng = pkg.Engine(0, reorthogonalise=1)
-    eng.gen_rmat(20, n, 20_000_000, 1234)
+    eng.gen_rmat(20, n, C2_DRAWS, 1234)
     rp, ci = eng.get_graph_csr()
     x0 = np.ones(n)
     R = O.referee_expm(rp, ci, k, x0, caps=CAPS, reorth=1)
@@ -188,7 +190,7 @@ def test_reorthogonalised_variant(pkg, oracle):
     # by then) but not with every 3 (tools/reorth_probe.py, profiles/r3_reorth_probe.txt).
     for e, expect_engine_bad in ((2, None), (3, True)):
         eng = pkg.Engine(0, reorthogonalise=e)
-        eng.gen_rmat(20, n, 20_000_000, 1234)
+        eng.gen_rmat(20, n, C2_DRAWS, 1234)
         a, b, _, xn, _ = eng.lanczos(x0, k, want_q=False)
         a_ref, b_ref, Q_ref, xn_ref = O.lanczos_arnoldi(rp, ci, k, x0, every=e)
         bad_engine = rel_inf(eng.multout(shift_weights(O, a, b, xn, cap=40.0)), R["ans"][1])

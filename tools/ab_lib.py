@@ -8,7 +8,7 @@ import numpy as np
 
 path, work = sys.argv[1], sys.argv[2]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-WORK = {"c2": (1, 20, 1 << 20, 20_000_000), "c3": (1, 24, 10_000_000, 200_000_000), "er": (0, 0, 10_000_000, 100_000_000),
+WORK = {"c2": (1, 20, 1 << 20, 21_615_022), "c3": (1, 24, 10_000_000, 207_184_357), "er": (0, 0, 10_000_000, 100_000_104),
         "er1m": (0, 0, 1_000_000, 10_000_000)}
 kind, scale, n, draws = WORK[work]
 L = ctypes.CDLL(path)

@@ -4,9 +4,10 @@ the download of alpha / beta.  C3 by default."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, __graft_entry__ as ge
+from bench import C2_DRAWS, C3_DRAWS
 pkg = ge.load_pkg()
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
-scale, n, draws, k = {"c3": (24, 10_000_000, 200_000_000, 50), "c2": (20, 1 << 20, 20_000_000, 50)}[wl]
+scale, n, draws, k = {"c3": (24, 10_000_000, C3_DRAWS, 50), "c2": (20, 1 << 20, C2_DRAWS, 50)}[wl]
 for scan in (1, 0):
     e = pkg.Engine(0, start_vector_scan=scan)
     e.gen_rmat(scale, n, draws, 1234)

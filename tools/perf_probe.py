@@ -11,10 +11,10 @@ import __graft_entry__ as ge
 pkg = ge.load_pkg()
 if os.environ.get("LZX_PROBE_DBG_LIB"):   # A/B against another build of the debug library (same box, same job)
     pkg.DBG_LIB_PATH = os.environ["LZX_PROBE_DBG_LIB"]
-WORK = {"c2": (20, 1 << 20, 20_000_000), "c3": (24, 10_000_000, 200_000_000), "c2b": (20, 1_000_000, 20_000_000),
+WORK = {"c2": (20, 1 << 20, 21_615_022), "c3": (24, 10_000_000, 207_184_357), "c2b": (20, 1_000_000, 20_000_000),
         "big": (25, 30_000_000, 600_000_000), "mid": (22, 4_000_000, 80_000_000), "c5": (27, 100_000_000, 2_000_000_000),
         # Erdos-Renyi (scale 0 = the ER generator): north_star's uniform family
-        "er": (0, 10_000_000, 100_000_000), "er1m": (0, 1_000_000, 10_000_000), "er4m": (0, 4_000_000, 40_000_000)}
+        "er": (0, 10_000_000, 100_000_104), "er1m": (0, 1_000_000, 10_000_000), "er4m": (0, 4_000_000, 40_000_000)}
 
 
 def run(name, opts_list, k=20):

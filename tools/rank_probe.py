@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 
 pkg = ge.load_pkg()
-scale, n, draws = 24, 10_000_000, 200_000_000
+from bench import C3_DRAWS
+scale, n, draws = 24, 10_000_000, C3_DRAWS
 src = pkg.Engine(0, propagation_blocking=0)
 src.gen_rmat(scale, n, draws, 1234)
 rp, ci = src.get_graph_csr()
