@@ -165,7 +165,9 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-        sys.stdout.write(child.stdout)
+        # rank 0's JSON line on stdout; whatever else the ranks printed there (gloo announces its connections on stdout) on stderr
+        for ln in child.stdout.splitlines():
+            print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
         sys.stdout.flush()
         sys.exit(child.returncode)
     if world != args.gpus:
@@ -317,12 +319,13 @@ def main():
         return res
 
     def measure(e):
-        """W untimed iterations (a decomposition of their own), then the workload's k-step decomposition is prepared and
+        """W untimed iterations (of a k-step decomposition of their own), then the workload's k-step decomposition is prepared and
         exactly K of its iterations run between barrier + synchronise on both sides, max over ranks; the other k - K follow
         outside the clock."""
         if W > 0:
-            e.lanczos_prepare(x0, W)
-            e.lanczos_run()
+            # a decomposition of the timed one's shape (the resident basis is sized for k columns once, here), W of its iterations
+            e.lanczos_prepare(x0, k_cfg)
+            e.lanczos_run_steps(W)
         t_in = time.perf_counter()
         e.lanczos_prepare(x0, k_cfg)     # x0 uploaded, q_0 in HBM, basis sized for k columns: inputs resident before the clock starts
         barrier(e)

@@ -2,7 +2,7 @@
 //
 // Why: past the 4 MiB per-XCD L2 a random 8-byte gather of x costs a whole 128-byte fabric transaction
 // (tools/gather_bench.hip: 55 Ggather/s = 7 TB/s of traffic), and even L2-resident gathers top out near
-// 200 Ggather/s, so the plain CSR gather moves 8x the algorithmic bytes (profiles/r1_c3_baseline_pmc.json: 15 GB per
+// 200 Ggather/s, so the plain CSR gather moves 8x the algorithmic bytes (profiles/archive/r1_c3_baseline_pmc.json: 15 GB per
 // SpMV on the 10 M-vertex graph).  Here the same work is two streaming passes around LDS.
 //
 // Bands and runs.  Column bands = 16 Ki positions of the exchange layout (one 128 KiB LDS tile of x).  Row bands =

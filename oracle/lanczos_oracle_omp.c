@@ -17,6 +17,8 @@
 #include <stdlib.h>
 
 int orc_omp_threads(void) { return omp_get_max_threads(); }
+/* (the OpenMP runtime may have been started by another library of the process long before: OMP_NUM_THREADS is read only then) */
+void orc_omp_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 static void spmv_omp(uint64_t n, const uint64_t *row_offset, const uint32_t *col_idx, const double *in, double *out)
 {

@@ -181,7 +181,11 @@ def lanczos_omp(row_offset, col_idx, k: int, x, threads: int = 0):
         L.orc_lanczos_omp.argtypes = [ctypes.c_uint64, _u64p, _u32p, ctypes.c_uint32, _f64p, _f64p, _f64p, _f64p]
         L.orc_lanczos_omp.restype = ctypes.c_int
         L.orc_omp_threads.restype = ctypes.c_int
+        L.orc_omp_set_threads.argtypes = [ctypes.c_int]
+        L.orc_omp_set_threads.restype = None
         _OMP = L
+    if threads > 0:
+        _OMP.orc_omp_set_threads(int(threads))
     n = len(row_offset) - 1
     x = np.ascontiguousarray(x, dtype=np.float64)
     alpha = np.zeros(k)
