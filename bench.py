@@ -418,6 +418,10 @@ def main():
                 # not `value`: the whole k-step decomposition with the host hand-over (x0 upload, basis set-up) and the
                 # download of alpha / beta included -- what a caller holding host buffers sees (rank 0's clock)
                 "iters_per_sec_including_host_transfers": k_cfg / (elapsed + m["t_rest"] + m["t_in"] + m["t_out"]),
+                # ... its parts on rank 0's clock, ms: lzx_lanczos_prepare_f64 (x0 in, q_0, basis sized) + barrier; the K timed iterations;
+                # the other k - K (a second lzx_lanczos_run_steps call + barrier); lzx_lanczos_fetch_f64 of alpha / beta
+                "host_hand_over_ms": {"prepare": 1e3 * m["t_in"], "timed_iterations": 1e3 * elapsed, "other_iterations": 1e3 * m["t_rest"],
+                                      "fetch_alpha_beta": 1e3 * m["t_out"]},
                 "lanczos_coefficients_finite": m["finite"],
                 # x0 = ones: alpha_0 = q_0' A q_0 = nnz / n exactly (a check of the run itself, not of parity -- that is tests/)
                 "alpha0_vs_closed_form_rel": abs(float(m["head"][0]) * gi["n"] / gi["nnz"] - 1.0) if gi["nnz"] else None,

@@ -23,7 +23,7 @@ PRODUCT_OPTIONS = ("hub_entries", "propagation_blocking", "overlap_exchange", "s
 # test-only shapes the product library accepts through lzx_test_set_shape (csrc/lzx_test_hooks.h): they select among code
 # paths the product contains (what large graphs get by themselves), so tests that force them still run liblzx.so
 SHAPE_OPTIONS = ("pb_reduce", "pb_target", "pb_unit", "pb_column_band", "pb_run_align", "pb_taper", "pb_dyn_share", "pb_carry_scan", "pb_scatter_nt", "pb_gather_grid", "pb_gather_nt", "spmv_wgs", "pb_group", "pb_group_force",
-                 "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1", "isolated_rows", "unnormalised_basis", "fuse_staged", "start_vector_scan")
+                 "narrow_slices", "tie_sort", "long_row", "item_len", "exchange_at_world_1", "isolated_rows", "unnormalised_basis", "fuse_staged", "start_vector_scan", "defer_finish")
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u32p = ctypes.POINTER(ctypes.c_uint32)

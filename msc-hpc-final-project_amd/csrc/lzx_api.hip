@@ -150,6 +150,7 @@ extern "C" int lzx_set_option(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "exchange_at_world_1")) c->force_multi = value > 0;
     else if (!strcmp(name, "phase_mask")) c->phase_mask_opt = value;
     else if (!strcmp(name, "start_vector_scan")) c->x0_scan_opt = value;
+    else if (!strcmp(name, "defer_finish")) c->defer_opt = value;
 #endif
     else LZX_FAIL(LZX_ERR_ARG, "lzx_set_option: unknown option '%s'", name);
     return LZX_OK;
@@ -190,6 +191,8 @@ extern "C" int lzx_test_set_shape(lzx_handle c, const char *name, int64_t value)
     else if (!strcmp(name, "fuse_staged")) c->fuse_opt = value;
     // 0: the start vector always crosses PCIe and its norm is always the serial chain (what round 5's look at x0 is compared with)
     else if (!strcmp(name, "start_vector_scan")) c->x0_scan_opt = value;
+    // 0: the blocked SpMV always launches k_pb_finish (default: the lazy loop's vector kernel stands in for it)
+    else if (!strcmp(name, "defer_finish")) c->defer_opt = value;
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_set_shape: unknown shape '%s'", name);
     return LZX_OK;
 }
@@ -205,6 +208,8 @@ extern "C" int lzx_test_get_shape(lzx_handle c, const char *name, int64_t *value
     else if (!strcmp(name, "placement_tried")) *value = c->place_tried;
     else if (!strcmp(name, "placement_kept")) *value = c->place_kept;
     else if (!strcmp(name, "start_vector_was_constant")) *value = c->x0_was_constant ? 1 : 0;
+    else if (!strcmp(name, "finish_deferrable")) *value = c->pb && c->pb_defer_ok ? 1 : 0;
+    else if (!strcmp(name, "finish_launched")) *value = c->pb && c->pb_finish_grid ? 1 : 0;
     else if (!strncmp(name, "placement_us_", 13) && name[13] >= '0' && name[13] <= '7' && !name[14]) *value = (int64_t)(c->place_ms[name[13] - '0'] * 1e3f);
     else LZX_FAIL(LZX_ERR_ARG, "lzx_test_get_shape: unknown shape '%s'", name);
     return LZX_OK;
@@ -615,6 +620,13 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
     // One rank in blocked mode (whose sums are already ordered differently from the reference's) takes the same form:
     // it saves k_scale's pass over v and a launch; in plain mode one rank keeps the reference's order bit for bit.
     const bool lazy = loop_is_lazy(c0);
+    // the lazy loop's vector kernel completes v for the rows of multi-item gather bands itself, so the blocked SpMV leaves its
+    // k_pb_finish launch out (lzx_ctx::pb_deferring; test shape defer_finish = 0 keeps the launch); every other consumer of v gets it
+    struct Deferring {
+        std::vector<lzx_ctx *> &cs;
+        Deferring(std::vector<lzx_ctx *> &h, bool on) : cs(h) { for (lzx_ctx *c : cs) c->pb_deferring = on && c->defer_opt != 0; }
+        ~Deferring() { for (lzx_ctx *c : cs) c->pb_deferring = false; }
+    } deferring(cs, lazy);
     const bool mail_ok = multi && lzx_comm_mail_usable(cs);
     // timing marks on every 4th iteration (every one when k is small); the sums below are scaled to all iterations run
     const u32 every = c0->marks_every_opt > 0 ? (u32)c0->marks_every_opt : (k >= 8 ? 4u : 1u);
@@ -879,7 +891,7 @@ static int lanczos_loop(std::vector<lzx_ctx *> &cs, u32 steps, lzx_stats *stats)
         memset(stats, 0, sizeof *stats);
         stats->loop_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats->iters = ran;
-        stats->spmv_kernels = c0->pb ? 3 + (c0->pb_finish_grid ? 1 : 0) : 1 + (c0->fin_grid > 0 ? 1 : 0);
+        stats->spmv_kernels = c0->pb ? 3 + (c0->pb_finish_grid && !(c0->pb_deferring && c0->pb_defer_ok) ? 1 : 0) : 1 + (c0->fin_grid > 0 ? 1 : 0);
         stats->spmv_bytes = spmv_algorithmic_bytes(c0);
         stats->spmv_ms_min = 1e300;
         for (size_t i = 1; i < mk.used; ++i) {

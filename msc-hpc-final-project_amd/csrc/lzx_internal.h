@@ -56,7 +56,7 @@ static constexpr u32 LZX_PB_CB = 16384;
 static constexpr u32 LZX_PB_CB_WIDE = 18432;   // test shape pb_column_band: 144 KiB of x per tile (nine 2 Ki-value staging rounds of the 1 024 threads)
 static constexpr u32 LZX_PB_RB = 1024;
 static constexpr u32 LZX_PB_TARGET = 32768;   // upper limit of the values per gather item (one wavefront each)
-static constexpr u32 LZX_PB_ALIGN = 8;        // (row band, column band) runs are padded to this many entries
+static constexpr u32 LZX_PB_ALIGN = 4;        // (row band, column band) runs are padded to this many values: one plain quad's two 16-byte stores (round 5; 8 = a 64-byte line until then: 4 % more values on the 10 M-vertex R-MAT graph, 5 % on the uniform one, profiles/r5_align_sweep.txt)
 static constexpr u32 LZX_PB_GATHER_BLOCK = 512;
 static constexpr u32 LZX_PB_GROUP = 16384;    // a row band of at most this many values is gathered by one wavefront (k_pb_gather)
 static constexpr unsigned long long LZX_PB_NT_BYTES = 128ull << 20;   // a gather value stream (values + slots) above this is read with non-temporal loads
@@ -255,6 +255,15 @@ struct lzx_ctx {
     u32 pb_gather_block = 512;
     u32 pb_n_items = 0, pb_n_multi = 0;
     u32 pb_gather_grid = 0, pb_finish_grid = 0;
+    // Round 5: in the lazy loop the sums k_pb_finish adds to v (rows of multi-item bands: their per-item totals + their split-row
+    // totals) are added by k_lazy_update where it reads w = v, and the launch is skipped.  pb_defer_ok: the graph's tables allow it
+    // (there is a finish launch, it serves multi-item bands only, no dynamic tail); pb_deferring: the loop that does it is running
+    // (set / reset by lanczos_loop: every other consumer of v -- lzx_spmv_f64, the plain loop, the re-orthogonalised one -- gets
+    // the launch).  d_pb_mrow[row] for row < pb_multi_limit: {row, first slot, items, slot stride}, items = 0: not a multi row.
+    uint4 *d_pb_mrow = nullptr;
+    u32 pb_multi_limit = 0;
+    bool pb_defer_ok = false, pb_deferring = false;
+    int64_t defer_opt = -1;            // test shape defer_finish: 0 = never defer
     double *d_pb_item_dot = nullptr;   // [pb_n_dyn] alpha partial of every drawn item of the gather pass's dynamic tail (closed in ticket order by k_pb_finish)
     u32 pb_n_static = 0, pb_n_dyn = 0; // gather items dealt to workgroups by the host / drawn from d_pb_gcounter at run time (k_pb_gather)
     u32 *d_pb_gcounter = nullptr;      // the dynamic tail's ticket counter (back to 0 at the end of every launch)
@@ -374,6 +383,16 @@ struct MailPeers { double *slot[64]; };   // where this handle's pair goes in ev
 int lzx_launch_reduce2_mail(lzx_ctx *c, const double *pa, u32 na, const double *pb, u32 nb, const MailPeers &peers, u32 world);
 int lzx_launch_iso_prepare(lzx_ctx *c, u32 k);                       // sum of squares of q_0 over the rows without an edge, c_0 = d_0 = 1
 int lzx_launch_iso_fill(lzx_ctx *c, u32 k);                          // q_j[i] = c_j q_0[i] for those rows, the columns below k that are not there yet
+// what k_lazy_update adds to w for the rows of multi-item bands when k_pb_finish was not launched (limit = 0: nothing)
+struct LazyDeferred {
+    const uint4 *mrow = nullptr;
+    u32 limit = 0;
+    const double *part = nullptr;
+    const u32 *item_first = nullptr;
+    const double *long_partial = nullptr;
+    const uint8_t *long_mode = nullptr;
+    u32 n_long = 0;
+};
 int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double *u, const double *q_prev, const double *scal2, int first,
                            double *alpha_out, double *beta_out, double *q_out, double *u_next, double *partials_out, u32 *np_out, const double *prev_div = nullptr,
                            float *f32_next = nullptr, u32 mail_world = 0);   // mail_world > 0: scal2 is a mailbox of that many [D, B] pairs

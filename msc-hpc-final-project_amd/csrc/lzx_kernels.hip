@@ -99,9 +99,21 @@ __global__ void __launch_bounds__(LZX_VEC_BLOCK)
 k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict__ u, const double *__restrict__ q_prev,
               const double *scal2, const double *pa, u32 na, const double *pb, u32 nb, int first, double *alpha_out,
               double *beta_out, double *q_out, double *u_next, double *partials_out, u32 n, double *iso, u32 iso_k, u32 iso_j,
-              const double *prev_div, float *f32_next, u32 mail_world)
+              const double *prev_div, float *f32_next, u32 mail_world, const LazyDeferred df)
 {
     __shared__ double sh[4];
+    // df.limit > 0 (blocked SpMV whose k_pb_finish launch was skipped, round 5): row r of a multi-item band still lacks the
+    // totals that launch adds to v -- its band's per-item sums in item order, then its split-row item totals -- exactly the
+    // operands, in the order, of k_pb_finish (lzx_pb.hip); their share of alpha was formed by the gather pass
+    auto deferred = [&](u32 row) -> double {
+        const uint4 m = df.mrow[row];
+        if (m.z == 0u) return 0.0;
+        double s = 0.0;
+        for (u32 k = 0; k < m.z; ++k) s += df.part[m.y + (size_t)k * m.w];
+        if (row < df.n_long && df.long_mode[row] == 1)
+            for (u32 it = df.item_first[row]; it < df.item_first[row + 1]; ++it) s += df.long_partial[it];
+        return s;
+    };
     double D, B;
     if (scal2 && mail_world) {   // in-process group: the ranks' pairs as their reduce kernels wrote them, added in rank order
         D = B = 0.0;
@@ -151,6 +163,10 @@ k_lazy_update(const double *__restrict__ w, u32 w_rows, const double *__restrict
         if (u_next) {
             // rows without an edge (the tail beyond w_rows) have (A u)_i = 0: not read, and the SpMV did not write them
             double2 t = i < w_rows ? *reinterpret_cast<const double2 *>(w + i) : make_double2(0.0, 0.0);
+            if (i < df.limit) {
+                t.x += deferred(i);
+                if (i + 1 < df.limit) t.y += deferred(i + 1);
+            }
             if (!first) {
                 t.x /= beta;
                 t.y /= beta;
@@ -517,7 +533,23 @@ static u32 vec_grid(const lzx_ctx *c)
     return need < 1 ? 1 : (need < cap ? need : cap);
 }
 
-u32 lzx_spmv_partials(const lzx_ctx *c) { return c->spmv_grid + (c->pb ? 0 : c->fin_grid) + lzx_pb_partials(c); }
+// (the partials of k_pb_finish come last: while its launch is deferred into k_lazy_update they are not there)
+u32 lzx_spmv_partials(const lzx_ctx *c) { return c->spmv_grid + (c->pb ? 0 : c->fin_grid) + lzx_pb_partials(c) - (c->pb_deferring && c->pb_defer_ok ? c->pb_finish_grid : 0u); }
+
+static LazyDeferred lazy_deferred(const lzx_ctx *c)
+{
+    LazyDeferred d;
+    if (c->pb && c->pb_deferring && c->pb_defer_ok) {
+        d.mrow = c->d_pb_mrow;
+        d.limit = c->pb_multi_limit;
+        d.part = c->d_pb_part;
+        d.item_first = c->d_item_first;
+        d.long_partial = c->d_long_partial;
+        d.long_mode = c->d_pb_long_multi;
+        d.n_long = c->n_long64;
+    }
+    return d;
+}
 
 template <int HUB, bool NT>
 static int launch_spmv_t(lzx_ctx *c, const SpmvArgs &a, hipStream_t st)
@@ -665,7 +697,7 @@ int lzx_launch_lazy_update(lzx_ctx *c, const double *w, u32 w_rows, const double
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, scal2, nullptr, 0u, nullptr, 0u,
                        first, alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next, mail_world);
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next, mail_world, lazy_deferred(c));
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;
@@ -678,7 +710,7 @@ int lzx_launch_lazy_update_local(lzx_ctx *c, const double *w, u32 w_rows, const 
     const u32 g = vec_grid(c);
     hipLaunchKernelGGL(k_lazy_update, dim3(g), dim3(LZX_VEC_BLOCK), 0, c->stream, w, w_rows, u, q_prev, nullptr, pa, na, pb, nb, first,
                        alpha_out, beta_out, q_out, u_next, partials_out, c->iso_on ? c->rows_live : c->n_loc_pad,
-                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next, 0u);
+                       c->iso_on ? c->d_iso : nullptr, c->iso_cap, (u32)(alpha_out - c->d_alpha), prev_div, f32_next, 0u, lazy_deferred(c));
     LZX_HIP(hipGetLastError());
     *np_out = g + (c->iso_on ? 1u : 0u);
     return LZX_OK;

@@ -18,10 +18,10 @@
 //       piece.  Pieces that close at entry e of their lane form plane e of the step and are written lane-compacted
 //       (ballot + mbcnt): every store instruction writes one contiguous stretch, no prefix scan, and the matching
 //       row slots are static.  Several pieces of one row are simply added by the gather pass.
-//     PLAIN runs (shorter): padded to 8 entries; a lane takes a QUAD of four entries (one 8-byte load of their
+//     PLAIN runs (shorter): padded to whole quads (LZX_PB_ALIGN = 4 entries); a lane takes a QUAD of four entries (one 8-byte load of their
 //       columns-in-band, one 4-byte load of the quad's value slot), looks the four values up and writes them with
 //       two 16-byte stores (padding reads a zero kept behind the staged band).
-//     Value slots are in gather order, so a run is one contiguous, 64-byte aligned stretch of writes.
+//     Value slots are in gather order, so a run is one contiguous, 32-byte aligned stretch of writes.
 //   gather (k_pb_gather): a row band's values are cut into items of up to ~256 Ki values; one WORKGROUP per item, its
 //     eight wavefronts taking the item's 128-value blocks round-robin (the workgroup streams 8 consecutive KiB of
 //     values + 2-byte LDS slots at a time) and adding each value into a wave-private LDS y tile with ds_add_f64.  The
@@ -118,7 +118,7 @@ __global__ void k_pb_run_format(const u32 *runstart, u32 nruns, u64 count, u32 m
     epad[r] = red ? ((len + LZX_PBR_STEP - 1) & ~(LZX_PBR_STEP - 1)) : 0u;
 }
 
-// Values a run hands to the gather pass, padded to `align` (so every run starts on a 64-byte boundary): the pieces of
+// Values a run hands to the gather pass, padded to `align` (so every run starts on a quad's 32-byte boundary): the pieces of
 // a reduced run (step_excl = exclusive scan of the pieces per step), the entries of a plain one.
 __global__ void k_pb_run_values(const u32 *runstart, u32 nruns, u64 count, const uint8_t *fmt, const u32 *estart,
                                 const u32 *step_excl, u32 align, u32 *vcount)
@@ -683,16 +683,18 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
     // per SpMV become two.  Same operands in the same order as k_pb_finish added them: v = (v + y) + s -- in a short loop BEHIND the
     // fold (inside it the extra live values cost the 128-VGPR build six spills).
     // first..first + stride * m: the rows THIS thread has just folded (it re-reads its own stores); almost every band lies beyond
-    // n_long, where the wave-uniform test ends the matter
-    auto close_split_rows = [&](u32 row0, u32 rows, u32 first, u32 stride, double &dot) {
+    // n_long, where the wave-uniform test ends the matter.  mode 0: rows of a single-item band -- v and alpha; mode 1: rows of a
+    // multi-item band, called by the band's FIRST item -- alpha only (their v is closed by k_pb_finish or, deferred, by
+    // k_lazy_update, which add the same totals)
+    auto close_split_rows = [&](u32 row0, u32 rows, u32 first, u32 stride, double &dot, u32 mode) {
         if (row0 >= n_long) return;
         const u32 lim = min(rows, n_long - row0);
         for (u32 j = first; j < lim; j += stride) {
             const u32 row = row0 + j;
-            if (long_mode[row] != 0) continue;
+            if (long_mode[row] != mode) continue;
             double sl = 0.0;
             for (u32 it = item_first[row]; it < item_first[row + 1]; ++it) sl += long_partial[it];
-            v[row] += sl;
+            if (mode == 0) v[row] += sl;
             dot += sl * q_loc[row];
         }
     };
@@ -769,7 +771,8 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
         } else if (item.w != LZX_PB_ITEM_NONE) {
             const u32 R = item.x;
             const u32 r0 = band_row0[R];
-            o[0] = item.y; o[1] = item.z; o[2] = r0; o[3] = band_row0[R + 1] - r0; o[4] = band_rep[R]; o[6] = 1u;
+            o[0] = item.y; o[1] = item.z; o[2] = r0; o[3] = band_row0[R + 1] - r0; o[4] = band_rep[R];
+            o[6] = 1u + (item.y == band_beg[R] ? 2u : 0u);   // + 2: the band's first item (it forms the alpha share of the band's split rows)
         }
     }
     __syncthreads();
@@ -886,7 +889,7 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                         }
                     }
                 }
-                close_split_rows(row0, rows, lane, 64u, dot);
+                close_split_rows(row0, rows, lane, 64u, dot, 0u);
                 GSTAMP(t_fold);
             }
             continue;
@@ -924,7 +927,15 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     }
                     v[row0] = vr;
                 } else {
+                    // one of several items of its band: the total is added to v later (k_pb_finish / k_lazy_update); its share of
+                    // alpha is formed here, by the workgroup the static schedule gave the item to
                     part[item_w] = t;
+                    dot += t * q_loc[row0];
+                    if ((r_live & 2u) && row0 < n_long && long_mode[row0] == 1) {
+                        double sl = 0.0;
+                        for (u32 it = item_first[row0]; it < item_first[row0 + 1]; ++it) sl += long_partial[it];
+                        dot += sl * q_loc[row0];
+                    }
                 }
             }
             continue;
@@ -988,14 +999,16 @@ k_pb_gather(const uint4 *items, u32 n_static, u32 n_dyn, u32 *counter, double *i
                     }
                 }
             }
-            close_split_rows(row0, rows, tid, LZX_PB_GATHER_BLOCK, dot);
+            close_split_rows(row0, rows, tid, LZX_PB_GATHER_BLOCK, dot, 0u);
         } else {
             for (u32 j = tid; j < rows; j += LZX_PB_GATHER_BLOCK) {
                 double y = 0.0;
                 for (u32 w = 0; w < WAVES; ++w)
                     for (u32 t = 0; t < rep; ++t) y += lds[(size_t)w * TILE + j * rep + t];
                 part[item_w + j] = y;
+                dot += y * q_loc[row0 + j];   // (see the single-row item above)
             }
+            if (r_live & 2u) close_split_rows(row0, rows, tid, LZX_PB_GATHER_BLOCK, dot, 1u);
         }
         GSTAMP(t_fold);
     }
@@ -1055,8 +1068,8 @@ k_pb_finish(const uint4 *multi /*[n]: row, first slot, items, slot stride*/, u32
         for (u32 k = 0; k < m.z; ++k) s += part[m.y + (size_t)k * m.w];
         if (row < n_long)   // a split row of a multi-item band: one thread owns the row's update
             for (u32 it = item_first[row]; it < item_first[row + 1]; ++it) s += long_partial[it];
-        v[row] += s;
-        dot = s * q_loc[row];
+        v[row] += s;        // (the row's share of alpha was formed by the gather pass's items, round 5: this launch only completes v,
+                            //  which is why k_lazy_update can do it instead -- lzx_ctx::pb_deferring)
     } else if (t - n_multi < n_long && long_mode[t - n_multi] == 2) {
         const u32 r = t - n_multi;
         double s = 0.0;
@@ -1164,6 +1177,9 @@ void lzx_pb_release(lzx_ctx *c)
     pb_free(c->d_pb_multi);
     pb_free(c->d_pb_part);
     pb_free(c->d_pb_long_multi);
+    pb_free(c->d_pb_mrow);
+    c->pb_multi_limit = 0;
+    c->pb_defer_ok = c->pb_deferring = false;
     pb_free(c->d_pbr_code);
     pb_free(c->d_pbr_base);
     c->pb = false;
@@ -1318,7 +1334,11 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     {
         // a workgroup (8 wavefronts) per item, two workgroups per CU, a few items each
         const u64 want = total / ((u64)c->cu_count * 8);
-        target = (u32)std::min<u64>(8 * LZX_PB_TARGET, std::max<u64>(8192, (want + 1023) & ~1023ull));
+        // ... nor so short that a band of a small problem is cut into several items (each cut band costs its rows a trip through
+        // the per-item totals and the SpMV a k_pb_finish launch): from 32 Ki values per item (round 5, tools/target_sweep.py,
+        // profiles/r5_target_sweep.txt: 1 M-vertex graph 0.0626 -> 0.0594 ms per SpMV, rank 0 of 8 of the 10 M-vertex graph
+        // 0.111 -> 0.102 ms, rank 0 of 4 and of 2 unchanged; the floor was 8 Ki)
+        target = (u32)std::min<u64>(8 * LZX_PB_TARGET, std::max<u64>(LZX_PB_TARGET, (want + 1023) & ~1023ull));
     }
     if (c->pb_target_opt > 0) target = (u32)c->pb_target_opt;
     // entries per scatter unit: every unit restages its column band while its CU does nothing else, and a workgroup
@@ -1437,8 +1457,8 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     LZX_TRY(pb_scan(st, false, d_step_cnt, d_step_excl, (u64)nsteps + 1));
     ar.drop(d_step_cnt);
 
-    // 4. value positions: every run gets its values (pieces or entries) padded to whole 64-byte lines, in gather order
-    const u32 run_align = (c->pb_align_opt == 8 || c->pb_align_opt == 16) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
+    // 4. value positions: every run gets its values (pieces or entries) padded to whole quads (32 bytes), in gather order
+    const u32 run_align = (c->pb_align_opt == 4 || c->pb_align_opt == 8 || c->pb_align_opt == 16) ? (u32)c->pb_align_opt : LZX_PB_ALIGN;
     u32 *d_vcount = nullptr, *d_vpos = nullptr;
     LZX_TRY(ar.get(&d_vcount, (u64)nruns + 1)); LZX_TRY(ar.get(&d_vpos, (u64)nruns + 1));
     LZX_HIP(hipMemsetAsync(d_vcount + nruns, 0, sizeof(u32), st));
@@ -1796,6 +1816,18 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
         LZX_HIP(hipStreamSynchronize(st));
     }
     LZX_TRY(pb_alloc(&c->d_pb_items, items.size())); LZX_TRY(pb_alloc(&c->d_pb_multi, multi.size())); LZX_TRY(pb_alloc(&c->d_pb_part, slots));
+    {   // the multi rows by ROW (k_lazy_update's look-up when it stands in for k_pb_finish): {row, first slot, items, slot stride}
+        u32 limit = 0;
+        for (size_t i = 0; i < multi.size(); i += 4) limit = std::max(limit, multi[i] + 1);
+        limit = (limit + 1u) & ~1u;   // (k_lazy_update takes rows in pairs)
+        std::vector<u32> mrow((size_t)limit * 4, 0u);
+        for (size_t i = 0; i < multi.size(); i += 4)
+            for (int u = 0; u < 4; ++u) mrow[(size_t)multi[i] * 4 + u] = multi[i + u];
+        c->pb_multi_limit = limit;
+        LZX_TRY(pb_alloc(&c->d_pb_mrow, (u64)std::max<u32>(limit, 1u)));
+        if (limit) LZX_HIP(hipMemcpyAsync(c->d_pb_mrow, mrow.data(), sizeof(u32) * mrow.size(), hipMemcpyHostToDevice, st));
+        LZX_HIP(hipStreamSynchronize(st));
+    }
     if (!items.empty())
         LZX_HIP(hipMemcpyAsync(c->d_pb_items, items.data(), sizeof(u32) * items.size(), hipMemcpyHostToDevice, st));
     if (!multi.empty())
@@ -1821,6 +1853,9 @@ int pb_prepare_impl(lzx_ctx *c, const u32 *d_code, const u32 *d_old_of_local, co
     (void)waves_per_wg;
     // k_pb_finish: the rows of multi-item bands, then (only when some split row is covered by no gather item) a thread per split row
     c->pb_finish_grid = (c->pb_n_multi + (n_uncovered ? c->n_long64 : 0u) + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK;
+    // ... and the lazy loop may leave that launch out (k_lazy_update adds the totals where it reads v) when multi-item bands are all
+    // it serves: no uncovered split row, no drawn items whose alpha shares it closes
+    c->pb_defer_ok = c->pb_n_multi > 0 && n_uncovered == 0 && c->pb_n_dyn == 0;
     if (c->pb_n_dyn) c->pb_finish_grid = std::max<u32>(c->pb_finish_grid, (c->pb_n_dyn + LZX_VEC_BLOCK - 1) / LZX_VEC_BLOCK);   // + the drawn items' alpha partials
     return LZX_OK;
 }
@@ -1958,7 +1993,7 @@ int lzx_pb_launch(lzx_ctx *c, const double *x, const double *q_loc, double *v, d
         // experiment: scatter pass alone
     } else if (!gathered)
         LZX_TRY(nt ? gather(k_pb_gather<false, true>, nullptr) : gather(k_pb_gather<false, false>, nullptr));
-    if (c->pb_finish_grid)
+    if (c->pb_finish_grid && !(c->pb_deferring && c->pb_defer_ok))   // (deferred: k_lazy_update completes v, lzx_ctx::pb_deferring)
         hipLaunchKernelGGL(k_pb_finish, dim3(c->pb_finish_grid), dim3(LZX_VEC_BLOCK), 0, c->stream,
                            reinterpret_cast<const uint4 *>(c->d_pb_multi), c->pb_n_multi, c->d_pb_part, c->d_item_first,
                            c->d_long_partial, c->d_pb_long_multi, c->n_long64, v, q_loc, partials + c->pb_gather_grid,

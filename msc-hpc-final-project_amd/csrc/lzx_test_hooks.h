@@ -11,7 +11,8 @@
 // resident basis holds q_j instead of u_j), "fuse_staged" (0: staged-columns kernel in a launch of its own; 1: behind the
 // scatter units of the shared launch instead of ahead of them), "start_vector_scan" (0: lzx_lanczos_prepare_f64 always uploads x0 and
 // sums its squares in one serial chain; default: one look at x0 first -- a constant vector is filled on the device, a sum that is
-// exact in any order is formed by several threads).
+// exact in any order is formed by several threads), "defer_finish" (0: the blocked SpMV always launches k_pb_finish; default: in the lazy loop
+// k_lazy_update adds the totals of multi-item gather bands where it reads v and the launch is left out).
 #pragma once
 #include <stdint.h>
 #include "lzx.h"
@@ -22,7 +23,8 @@ int lzx_test_set_shape(lzx_handle h, const char *name, int64_t value);
 // what shape the tables of the handle's graph took: "gather_items_dealt" / "gather_items_drawn" (static lists / dynamic tail of
 // the gather pass), "gather_workgroups", "placement_tried" / "placement_kept" / "placement_us_<i>" (option placement_trials: candidates of
 // the value stream timed at the last hand-over, the one kept, the SpMV time of candidate i in microseconds), "start_vector_was_constant"
-// (the last prepared x0 was filled on the device instead of uploaded)
+// (the last prepared x0 was filled on the device instead of uploaded), "finish_launched" / "finish_deferrable" (the graph's blocked SpMV has a
+// k_pb_finish launch / the lazy loop may leave it out)
 #ifdef __cplusplus
 extern "C"
 #endif

@@ -42,7 +42,7 @@ def test_c2_full_size(pkg, oracle):
     eng = pkg.Engine(0)
     eng.gen_rmat(20, 1 << 20, C2_DRAWS, 1234)          # BASELINE C2
     gi = eng.info()
-    assert gi["n"] == 1 << 20 and 36_000_000 < gi["nnz"] < 40_000_000
+    assert gi["n"] == 1 << 20 and gi["nnz"] == 40_000_000          # 20 M distinct undirected edges: BASELINE's count (bench.py: C2_DRAWS)
     rp, ci = eng.get_graph_csr()
     st = check_properties(eng, gi["n"], 8, np.random.default_rng(2), spmv_ref=lambda x: O.spmv(rp, ci, x))
     assert st["spmv_bytes"] == 4 * gi["nnz"] + 4 * (gi["n"] + 1) + 16 * gi["n"]
@@ -86,8 +86,8 @@ def test_c2_k50_recurrence(pkg, oracle):
 def test_eight_ranks_in_process_c2(pkg, oracle):
     """The 8-rank layout of C4 (rows dealt by degree rank, only the vertices that have an edge exchanged, the
     two-chunk exchange that overlaps the blocked SpMV and the single all-gather) on 8 in-process handles sharing this
-    box's one GPU, on the C2 graph, against the oracle: SpMV 1e-13, first coefficients, recurrence of every column,
-    shifted centrality vector 1e-10.  The transport here is device-to-device copies; under torch.distributed.run the
+    box's one GPU, on the C2 graph, against the oracle: SpMV 1e-13, first coefficients, recurrence of every column; the
+    shifted centrality vector against the extended-precision referee (1e-10, and no worse than 1.5 x the oracle).  The transport here is device-to-device copies; under torch.distributed.run the
     same two operations are RCCL calls (csrc/lzx_comm.hip)."""
     from test_gpu_parity import REL_INF_TOL, check_leading_coefficients, check_recurrence, rel_inf, shift_weights
     O = oracle
@@ -95,6 +95,12 @@ def test_eight_ranks_in_process_c2(pkg, oracle):
     rp, ci = O.gen_rmat(20, n, C2_DRAWS, 1234)
     a_ref, b_ref, Q_ref, xn_ref = O.lanczos(rp, ci, k, np.ones(n), q_colmajor=True)
     ref = shift_weights(O, a_ref, b_ref, xn_ref) @ Q_ref
+    # On this graph serial/'s own loop is not at 1e-10 even at k = 6 (its one-accumulator sums over 10^6 terms: 1.35e-10 from the
+    # extended-precision referee on the 20 M-edge graph, 4.7e-11 on the 18.6 M-edge one rounds 1-4 used), so the centrality vector
+    # is judged the way tests/test_gpu_referee.py judges k = 50: against the referee, the engine no worse than 1.5 x the oracle,
+    # and at 1e-10 wherever the oracle is
+    exact = O.referee_expm(rp, ci, k, np.ones(n), caps=(40.0,))["ans"][0]
+    e_orc = rel_inf(ref, exact)
     x = np.random.default_rng(8).random(n)
     y_ref = O.spmv(rp, ci, x)
     recv = {}
@@ -112,7 +118,9 @@ def test_eight_ranks_in_process_c2(pkg, oracle):
         assert xn == xn_ref
         check_leading_coefficients(a, b, a_ref, b_ref, ("local8", overlap, sparse), n=n)
         check_recurrence(O, rp, ci, a, b, Q, ("local8", overlap))
-        assert rel_inf(grp.multout(shift_weights(O, a, b, xn)), ref) <= REL_INF_TOL
+        e_dev = rel_inf(grp.multout(shift_weights(O, a, b, xn)), exact)
+        assert e_dev <= 1.5 * e_orc + 1e-13 and (e_orc > REL_INF_TOL or e_dev <= REL_INF_TOL), (overlap, sparse, e_dev, e_orc)
+        assert e_dev <= REL_INF_TOL, (overlap, sparse, e_dev)     # (the engine's tree-shaped sums: measured 1e-12)
         grp.close()
     # the sparse second chunk: a rank receives only what its rows reference (dense: 7 slices of the active prefix)
     assert recv[(1, 0)] == recv[(0, 1)] == 7 * gi["exchange_slice"]
@@ -121,7 +129,7 @@ def test_eight_ranks_in_process_c2(pkg, oracle):
 
 
 def test_eight_ranks_in_process_c3(pkg, oracle):
-    """BASELINE C4's partition on ITS OWN graph (VERDICT round 3, next 1 b): the 10 M-vertex / 386 M-entry R-MAT graph of C3 / C4
+    """BASELINE C4's partition on ITS OWN graph (VERDICT round 3, next 1 b): the 10 M-vertex / 400 M-entry R-MAT graph of C3 / C4
     dealt over 8 in-process handles that share this box's one GPU (8 x ~3 GB), against the oracle: one SpMV of a random vector at
     the per-row bound of test_c3_full_size_properties, the leading coefficients, the three-term recurrence of every column at
     k = 4 -- with the two-chunk exchange in its sparse and its dense form and with the single all-gather.  The transport is
@@ -195,7 +203,7 @@ def test_c3_full_size_properties(pkg, oracle):
     eng = pkg.Engine(0)
     eng.gen_rmat(24, 10_000_000, C3_DRAWS, 1234)       # BASELINE C3 / C4 graph
     gi = eng.info()
-    assert gi["n"] == 10_000_000 and 380_000_000 < gi["nnz"] < 400_000_000
+    assert gi["n"] == 10_000_000 and gi["nnz"] == 400_000_000       # 200 M distinct undirected edges (bench.py: C3_DRAWS)
     # one SpMV of a non-constant vector against the ORACLE (the row-sum check below is exact but blind to which x
     # entry a column reads): all 360 column bands of the blocked path, split rows included
     rp, ci = eng.get_graph_csr()
@@ -225,7 +233,7 @@ def test_er_full_size(pkg, oracle):
     eng = pkg.Engine(0)
     eng.gen_er(n, draws, 1234)
     gi = eng.info()
-    assert gi["n"] == n and 199_000_000 < gi["nnz"] <= 2 * draws and gi["max_degree"] < 100
+    assert gi["n"] == n and gi["nnz"] == 200_000_000 and gi["max_degree"] < 100   # 100 M distinct undirected edges (bench.py: ER_DRAWS)
     rp, ci = eng.get_graph_csr()
     x = np.random.default_rng(44).random(n)
     y, y_ref = eng.spmv(x), O.spmv(rp, ci, x)

@@ -214,3 +214,36 @@ def test_start_vector_hand_over_fast_paths(pkg, oracle):
             assert np.array_equal(a1, a0) and np.array_equal(b1, b0) and np.array_equal(Q1, Q0), (name, mode)
         fast.close()
         plain.close()
+
+
+def test_finish_launch_deferred_into_the_vector_kernel(pkg, oracle):
+    """Round 5: on graphs whose row bands are cut into several gather items the blocked SpMV ended with a
+    fourth launch, k_pb_finish, that added the per-item totals (and the split rows' item totals) to v.  In the lazy loop
+    k_lazy_update now adds those totals where it reads v and the launch is left out; the rows' share of alpha is formed by the gather
+    pass's items either way.  Same operands in the same order: every coefficient and basis column equals the undeferred form's
+    (test shape defer_finish = 0) BIT FOR BIT -- on one rank and on three, with split rows inside multi-item bands -- and lzx_spmv_f64,
+    which hands v out, still gets the launch."""
+    O = oracle
+    rp, ci = O.gen_rmat(17, 120000, 2500000, 9)
+    n = len(rp) - 1
+    x = np.random.default_rng(3).random(n)
+    y_ref = O.spmv(rp, ci, x)
+    # small gather items: many multi-item bands; a low split-row threshold: split rows inside them
+    shape = dict(propagation_blocking=1, hub_entries=512, pb_target=1024, long_row=24)
+    for world in (1, 3):
+        runs = {}
+        for defer in (1, 0):
+            g = pkg.Engine(0, defer_finish=defer, **shape) if world == 1 else pkg.LocalGroup([0] * world, defer_finish=defer, **shape)
+            g.set_graph_csr(rp, ci)
+            e0 = g if world == 1 else g.engines[0]
+            assert e0.shape("finish_launched") == 1 and e0.shape("finish_deferrable") == 1 and e0.info()["long_rows"] > 0
+            assert np.allclose(g.spmv(x), y_ref, rtol=1e-13, atol=0)                # v complete for those who read it
+            a, b, Q, xn, st = g.lanczos(np.ones(n), 12)
+            assert st["spmv_kernels"] == (3 if defer else 4), st
+            assert np.allclose(g.spmv(x), y_ref, rtol=1e-13, atol=0)                # ... also after a loop that deferred
+            runs[defer] = (a, b, Q)
+            g.close()
+        for u, w in zip(runs[1], runs[0]):
+            assert np.array_equal(u, w), world
+        a_ref, b_ref, _, _ = O.lanczos(rp, ci, 12, np.ones(n), want_q=False)
+        assert abs(runs[1][0][0] - a_ref[0]) <= 1e-12 * abs(a_ref[0]) and abs(runs[1][1][0] - b_ref[0]) <= 1e-12 * abs(b_ref[0])
