@@ -371,19 +371,37 @@ __device__ __forceinline__ double pbr_carry_scan(double tail, bool has)
 {
     double P = tail;
     u32 F = has ? 1u : 0u;
+    // (the addend is selected, not the sum: a lane whose segment is closed adds + 0.0, which changes nothing)
 #define LZX_SCAN_STEP(CTRL, RM)                          \
     {                                                    \
         const double ps = dpp_f64<CTRL, RM>(P);          \
         const u32 fs = dpp_u32<CTRL, RM>(F);             \
-        P = F ? P : P + ps;                              \
+        P += F ? 0.0 : ps;                               \
         F |= fs;                                         \
     }
-    LZX_SCAN_STEP(0x111, 0xf)   // row_shr:1
-    LZX_SCAN_STEP(0x112, 0xf)   // row_shr:2
-    LZX_SCAN_STEP(0x114, 0xf)   // row_shr:4
-    LZX_SCAN_STEP(0x118, 0xf)   // row_shr:8
-    LZX_SCAN_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
-    LZX_SCAN_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+    // Round 5: only the steps some segment needs.  A step of distance d adds something only to a lane whose d predecessors
+    // (itself included) hold no piece end; the holders are known as a lane mask, so that is a few scalar operations and a
+    // wave-uniform branch per step -- scalar work, where the step itself is seven vector instructions.  In a typical step of
+    // the 10 M-vertex graph (93 pieces in 64 lanes) nearly every lane holds a piece end and the scan shrinks to its last line.
+    // A skipped step would have added + 0.0 everywhere: the sums are the same.  (The tests against rows of 16 are left
+    // out -- row_shr does not cross them -- which can only run a step that was not needed.)
+    const unsigned long long nh = ~__ballot(has);           // lanes without a piece end
+    if (nh) {
+        LZX_SCAN_STEP(0x111, 0xf)   // row_shr:1
+        const unsigned long long q2 = nh & (nh << 1);       // lane i and lane i - 1
+        if (q2) {
+            LZX_SCAN_STEP(0x112, 0xf)   // row_shr:2
+            const unsigned long long q4 = q2 & (q2 << 2);   // lanes i .. i - 3
+            if (q4) {
+                LZX_SCAN_STEP(0x114, 0xf)   // row_shr:4
+                const unsigned long long q8 = q4 & (q4 << 4);
+                if (q8) LZX_SCAN_STEP(0x118, 0xf)   // row_shr:8
+            }
+        }
+        // across the rows of 16: a row's first lane without a piece end continues the row before it
+        if (nh & ((1ull << 16) | (1ull << 48))) LZX_SCAN_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+        if (nh & ((1ull << 32) | (1ull << 48))) LZX_SCAN_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+    }
 #undef LZX_SCAN_STEP
     return dpp_f64<0x138, 0xf>(P);   // wave_shr:1: lane L takes lane L - 1's prefix (lane 0: nothing before it)
 }
@@ -444,7 +462,47 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
         // before it that holds a piece end; the lane holding the row's end starts its running sum from that slot.
         // One ds_add + one ds_read per lane and step, no shuffles, no scan.
         double *carry = tile + CB + 2 + wv * 66;
-        auto body = [&](const uint4 &c, u32 pos) {
+        // Round 5 form of the step (SCAN): one pass forms every piece's LOCAL sum (val[e], kept in registers) and, as what is left
+        // in the running sum behind the lane's last piece end, the tail the carry scan needs; the stores follow the scan, and the
+        // lane's FIRST piece -- the one that continues a row from the lanes before -- takes the carried sum on its way out.
+        // Against the round-4 form (a masked tail pass, then the running sum started from the carry: kept below for the LDS-carry
+        // shape) that is a third fewer vector instructions per step: no `last`, no masked second pass over the eight values, the
+        // piece-end flags tested where they lie in the code words (an odd entry's flag is its word's sign bit) and held as lane
+        // masks.  The sums are the same up to the place of one addition: (x0 + x1 + ..) + carried instead of ((carried + x0) + x1) ..
+        auto body_scan = [&](const uint4 &c, u32 pos) {
+            const u32 w[4] = {c.x, c.y, c.z, c.w};
+            double xv[8];
+            bool f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xv[e] = tile[pbr_half(c, e) & 0x7fffu];
+                f[e] = (e & 1) ? ((int)w[e >> 1] < 0) : ((w[e >> 1] & 0x8000u) != 0u);
+            }
+            const bool has = ((c.x | c.y | c.z | c.w) & 0x80008000u) != 0u;
+            double pv[8];
+            double run = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                run += xv[e];
+                pv[e] = run;
+                run = f[e] ? 0.0 : run;
+            }
+            double carry = pbr_carry_scan(run, has);   // (only read by lanes that hold a piece end)
+            double *out = val + pos;   // wave-uniform: the step's first value slot
+            u32 done = 0;              // pieces of the planes before this one
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned long long m = __ballot(f[e]);
+                if (m) {               // scalar branch: steps of few long rows have mostly empty planes
+                    if (f[e]) {
+                        out[done + lanes_below(m)] = pv[e] + carry;
+                        carry = 0.0;
+                    }
+                    done += (u32)__popcll(m);
+                }
+            }
+        };
+        auto body_lds = [&](const uint4 &c, u32 pos) {
             double xv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) xv[e] = tile[pbr_half(c, e) & 0x7fffu];
@@ -497,7 +555,10 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
                 b[u] = (u32)__builtin_amdgcn_readfirstlane((int)sbase[s + u * W]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) body(c[u], b[u]);
+            for (int u = 0; u < 4; ++u) {
+                if (SCAN) body_scan(c[u], b[u]);
+                else body_lds(c[u], b[u]);
+            }
         }
         if (s < end) {   // up to three more steps: requested together (wave-uniform predicates), not one round trip each
             uint4 c[3];
@@ -511,7 +572,10 @@ pb_scatter_body(const u32 *unit, const uint4 *scode, const u32 *sbase, const uin
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u)
-                if (s + u * W < end) body(c[u], b[u]);
+                if (s + u * W < end) {
+                    if (SCAN) body_scan(c[u], b[u]);
+                    else body_lds(c[u], b[u]);
+                }
         }
     }
 
