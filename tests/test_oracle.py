@@ -153,3 +153,18 @@ def test_arnoldi_restatement(oracle):
     s = min(1.0, 40.0 / lam.max())
     got = (V @ (np.exp(s * (lam - lam.max())) * (xn1 * V[0, :]))) @ Q1
     assert np.abs(got - R["ans"][0]).max() <= 1e-10 * np.abs(R["ans"][0]).max()
+
+
+def test_all_core_companion_agrees_with_the_single_thread_loop():
+    """oracle/lanczos_oracle_omp.c (bench.py's optional "port-omp" CPU figure, SURVEY.md 8 d) is the same loop with OpenMP over rows and
+    elements: its spMV rows are summed as orc_spmv sums them; its inner products are OpenMP reductions, so the coefficients carry
+    another rounding -- a timing baseline, checked here only for being the same computation (leading coefficients to 1e-12, x_norm of
+    the ones vector exactly)."""
+    from oracle import oracle as O
+    rp, ci = O.gen_rmat(15, 30000, 300000, 7)
+    n = len(rp) - 1
+    a, b, _, xn = O.lanczos(rp, ci, 8, np.ones(n), want_q=False)
+    a2, b2, xn2, threads = O.lanczos_omp(rp, ci, 8, np.ones(n), threads=4)
+    assert threads == 4 and xn2 == xn
+    assert abs(a2[0] - a[0]) <= 1e-12 * abs(a[0]) and abs(b2[0] - b[0]) <= 1e-12 * abs(b[0])
+    assert np.allclose(a2[:4], a[:4], rtol=1e-9, atol=1e-9 * np.abs(a).max()) and np.allclose(b2[:3], b[:3], rtol=1e-9)
