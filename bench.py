@@ -429,8 +429,9 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("k_pb_scatter_spmv (scatter pass + staged columns from LDS, one launch; k_spmv + k_pb_scatter when they "
-                           "are launched separately) + k_pb_gather + k_pb_finish: propagation-blocked CSR SpMV (partial row "
-                           "sums cross the two passes) fused with the alpha partial") if gi["pb_entries"] else
+                           "are launched separately) + k_pb_gather: propagation-blocked CSR SpMV (partial row sums cross the two "
+                           "passes) fused with the alpha partial; the totals of row bands cut into several gather items are added "
+                           "by k_lazy_update in this loop, by k_pb_finish elsewhere") if gi["pb_entries"] else
                           "k_spmv (+ k_long_finish): CSR SpMV fused with the alpha partial",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS * (1 if one_gpu else world),
