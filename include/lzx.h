@@ -110,6 +110,12 @@ const char *lzx_last_error(void);
  *       any number of cards); exchanges are device-to-device copies.  Handles may share a GPU.      */
 int lzx_comm_unique_id(uint8_t id[128]);
 int lzx_comm_init_rank(lzx_handle h, const uint8_t id[128], int rank, int world);
+/* SURVEY.md 8(b)'s sketch of the boundary in one call: `n_devices` handles, out[i] on GPU device_ids[i] (NULL: GPUs 0 .. n_devices - 1;
+ * ids may repeat: handles may share a GPU), wired as ONE in-process communicator (lzx_create + lzx_comm_init_local) -- the
+ * reference's parallel-two-cards model (one process, cudaSetDevice per card: parallel-two-cards/lib/cu_lanczos.cu:73-190) for
+ * any number of cards.  Use the handles with the *_local entry points; destroy each with lzx_destroy.  On failure nothing is
+ * left behind and every out[i] is NULL.                                                                                       */
+int lzx_create_group(lzx_handle *out, int n_devices, const int *device_ids);
 int lzx_comm_init_local(lzx_handle *hs, int world);
 /*   lzx_comm_ipc_export / lzx_comm_ipc_init : one process per rank WITHOUT a collective library ("peer windows"): every
  *       rank's receive buffers are mapped into its peers (HIP inter-process memory handles), each rank's own kernel

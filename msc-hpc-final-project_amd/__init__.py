@@ -67,6 +67,7 @@ SYMBOLS = [
     ("lzx_comm_unique_id", ctypes.c_int, [_u8p]),
     ("lzx_comm_init_rank", ctypes.c_int, [_h, _u8p, ctypes.c_int, ctypes.c_int]),
     ("lzx_comm_init_local", ctypes.c_int, [_hp, ctypes.c_int]),
+    ("lzx_create_group", ctypes.c_int, [_hp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     ("lzx_comm_ipc_export", ctypes.c_int, [_h, _u8p]),
     ("lzx_comm_ipc_init", ctypes.c_int, [_h, _u8p, ctypes.c_int, ctypes.c_int]),
     ("lzx_set_graph_csr", ctypes.c_int, [_h, ctypes.c_uint64, ctypes.c_uint64, _u64p, _u32p]),
@@ -370,6 +371,23 @@ class LocalGroup:
         self.arr = (ctypes.c_void_p * self.world)(*[e.h for e in self.engines])
         _check(self.L.lzx_comm_init_local(self.arr, self.world), "lzx_comm_init_local", self.L)
         self.n = 0
+
+    @classmethod
+    def create(cls, devices):
+        """the same group made by ONE call of the C ABI (lzx_create_group: SURVEY.md 8(b)'s `lzx_create(out, n_devices, device_ids)`)"""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.world = len(devices)
+        self.arr = (ctypes.c_void_p * self.world)()
+        ids = (ctypes.c_int * self.world)(*devices)
+        _check(self.L.lzx_create_group(self.arr, self.world, ids), "lzx_create_group", self.L)
+        self.engines = []
+        for h in self.arr:
+            e = Engine.__new__(Engine)
+            e.h, e.debug, e.L, e.n = ctypes.c_void_p(h), False, self.L, 0
+            self.engines.append(e)
+        self.n = 0
+        return self
 
     def set_graph_csr(self, row_ptr, col_idx):
         for e in self.engines:

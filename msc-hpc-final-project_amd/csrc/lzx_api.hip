@@ -458,7 +458,7 @@ static X0Scan scan_start_vector(const double *x0, u64 n)
     if (all_int.load()) {
         double s = 0.0;
         for (u32 t = 0; t < T; ++t) s += part[t];   // integers: exact as long as the total is
-        if (s <= 9007199254740992.0) {
+        if (s < 9007199254740992.0) {   // strictly below 2^53: no partial sum of any order was rounded
             out.exact = true;
             out.sum_sq = s;
         }

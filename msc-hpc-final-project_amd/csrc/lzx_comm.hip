@@ -132,6 +132,22 @@ int lzx_comm_agree(lzx_ctx *c, bool ok, bool *all_ok)
     return LZX_OK;
 }
 
+extern "C" int lzx_create_group(lzx_handle *out, int n_devices, const int *device_ids)
+{
+    if (!out || n_devices < 1 || n_devices > 64) LZX_FAIL(LZX_ERR_ARG, "lzx_create_group: bad argument (1 .. 64 handles)");
+    for (int i = 0; i < n_devices; ++i) out[i] = nullptr;
+    int rc = LZX_OK;
+    for (int i = 0; i < n_devices && rc == LZX_OK; ++i) rc = lzx_create(&out[i], device_ids ? device_ids[i] : i);
+    if (rc == LZX_OK && n_devices > 1) rc = lzx_comm_init_local(out, n_devices);
+    if (rc != LZX_OK) {   // (the failing call's message stands)
+        for (int i = 0; i < n_devices; ++i) {
+            if (out[i]) lzx_destroy(out[i]);
+            out[i] = nullptr;
+        }
+    }
+    return rc;
+}
+
 extern "C" int lzx_comm_init_local(lzx_handle *hs, int world)
 {
     if (!hs || world < 1) LZX_FAIL(LZX_ERR_ARG, "lzx_comm_init_local: bad argument");

@@ -247,3 +247,28 @@ def test_finish_launch_deferred_into_the_vector_kernel(pkg, oracle):
             assert np.array_equal(u, w), world
         a_ref, b_ref, _, _ = O.lanczos(rp, ci, 12, np.ones(n), want_q=False)
         assert abs(runs[1][0][0] - a_ref[0]) <= 1e-12 * abs(a_ref[0]) and abs(runs[1][1][0] - b_ref[0]) <= 1e-12 * abs(b_ref[0])
+
+
+def test_create_group_in_one_call(pkg, oracle):
+    """SURVEY.md 8(b) sketched lzx_create(out, n_devices, device_ids); the ABI has one handle per GPU and three ways of wiring them.
+    lzx_create_group (round 5) is the sketch's call: n handles on the named GPUs (ids may repeat), wired as one in-process group --
+    the same numbers as handles made and wired one by one, and nothing left behind on a bad device id."""
+    import ctypes
+    O = oracle
+    rp, ci = O.gen_rmat(15, 30000, 400000, 4)
+    n = len(rp) - 1
+    x = np.random.default_rng(1).random(n)
+    one_call = pkg.LocalGroup.create([0, 0, 0])
+    by_hand = pkg.LocalGroup([0, 0, 0])
+    for g in (one_call, by_hand):
+        g.set_graph_csr(rp, ci)
+    assert [e.info()["rank"] for e in one_call.engines] == [0, 1, 2] and one_call.engines[2].info()["world"] == 3
+    assert np.array_equal(one_call.spmv(x), by_hand.spmv(x)) and np.allclose(one_call.spmv(x), O.spmv(rp, ci, x), rtol=1e-13, atol=0)
+    a1, b1, Q1, _, _ = one_call.lanczos(np.ones(n), 8)
+    a2, b2, Q2, _, _ = by_hand.lanczos(np.ones(n), 8)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(Q1, Q2)
+    one_call.close()
+    by_hand.close()
+    L = pkg.lib()
+    arr = (ctypes.c_void_p * 2)()
+    assert L.lzx_create_group(arr, 2, (ctypes.c_int * 2)(0, 4096)) != 0 and not arr[0] and not arr[1]
