@@ -66,12 +66,9 @@ static std::shared_ptr<deviceGraph> make_handles() {
   const std::vector<int> ids = lzx_host_devices();
   if (ids.empty()) throw std::runtime_error("adjMatrix: no usable GPU (lzx_device_count() == 0)");
   auto g = std::make_shared<deviceGraph>();
-  for (int id : ids) {
-    lzx_handle h = nullptr;
-    lzx_or_throw(lzx_create(&h, id), "lzx_create");
-    g->ranks.push_back(h);
-  }
-  if (g->ranks.size() > 1) lzx_or_throw(lzx_comm_init_local(g->ranks.data(), static_cast<int>(g->ranks.size())), "lzx_comm_init_local");
+  // one handle per card, wired as an in-process group: parallel-two-cards' per-card set-up (cu_lanczos.cu:73-112) in one call
+  g->ranks.assign(ids.size(), nullptr);
+  lzx_or_throw(lzx_create_group(g->ranks.data(), static_cast<int>(ids.size()), ids.data()), "lzx_create_group");
   return g;
 }
 
