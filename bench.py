@@ -551,9 +551,24 @@ def main():
             if all_ok(ok):
                 tune["overlapped"] = t_alt
                 tune["overlapped_received_MB_per_rank"] = 8e-6 * alt.info()["exchange_recv"]
+                # The trial's six iterations went through the two-chunk / sparse exchange itself (the self-check's products do not:
+                # lzx_spmv_f64 re-lays x out locally): their leading coefficients must be the single all-gather's, whether or not
+                # the overlapped form is then chosen (round 5, ADVICE r4: this comparison used to run only when it won)
+                dev = float("inf")
+                try:
+                    a6, b6, _ = alt.lanczos_fetch(6)
+                    head6 = np.concatenate([a6[:3], b6[:2]])
+                    dev = float(np.max(np.abs(head6 - m_single["head"]) / np.maximum(np.abs(m_single["head"]), 1e-300)))
+                except Exception as exc:
+                    print(f"[bench rank {rank}] overlapped exchange: cannot read the trial's coefficients: {exc}", file=sys.stderr, flush=True)
+                tune["overlapped_vs_single_coefficients_rel"] = dev
+                trial_agrees = all_ok(dev < 1e-9)
+                if not trial_agrees:
+                    print(f"[bench rank {rank}] overlapped exchange REJECTED after its trial: leading coefficients differ from the single "
+                          f"all-gather's by {dev:.2e}", file=sys.stderr, flush=True)
                 if rank == 0:
                     out["config"]["exchange_tuning_ms_per_iter"] = dict(tune)
-                if tune["overlapped"] < tune["single"] or os.environ.get("LZX_BENCH_FORCE_ALT") == "1":   # (the variable: tests run the comparison below)
+                if trial_agrees and (tune["overlapped"] < tune["single"] or os.environ.get("LZX_BENCH_FORCE_ALT") == "1"):   # (the variable: tests run the comparison below)
                     m_alt, ok = None, True
                     try:
                         m_alt = measure(alt)
