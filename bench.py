@@ -94,6 +94,26 @@ def pmc_traffic(workload: str, world: int):
         return None, None, None
 
 
+def byte_cost_model(workload: str, world: int, stream, spmv_ms: float):
+    """What the SpMV's MEASURED bytes would cost at this box's own streaming rates, the two directions priced apart: a read byte
+    at 1 / (the read-only probe's rate), a written byte at the rate the copy probe implies for its written half
+    (1 / w = 2 / copy - 1 / read: the copy moves as many bytes each way).  `measured_over_model` > 1 is what the kernels lose
+    against their bytes; `traffic` / algorithmic bytes is what the format loses against the matrix.  None without a PMC pass."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path)).get(workload) if world == 1 else None
+        rd, wr = d["read_bytes_per_launch"], d["written_bytes_per_launch"]
+        r, cp = stream[0] * 1e9, stream[1] * 1e9
+        inv_w = 2.0 / cp - 1.0 / r
+        if not (r > 0 and cp > 0 and inv_w > 0 and spmv_ms > 0):
+            return None
+        ms = (rd / r + wr * inv_w) * 1e3
+        return {"read_bytes": rd, "written_bytes": wr, "read_GBps": r / 1e9, "write_GBps": 1e-9 / inv_w, "ms": ms,
+                "measured_over_model": spmv_ms / ms}
+    except Exception:
+        return None
+
+
 def cpu_baseline(eng, O, budget_s: float = 10.0, omp_budget_s: float = 5.0):
     """The oracle's restatement of serial/ (single thread) on the SAME graph, a bounded number of iterations -- and, beside it
     ("optionally an OpenMP all-core SpMV number labelled as such"), the same loop with OpenMP over rows and
@@ -444,6 +464,9 @@ def main():
                 "traffic_source": pmc_traffic(args.workload, world)[1],
                 "traffic_build_id": pmc_traffic(args.workload, world)[2],
                 "traffic_measured_on_this_build": pmc_traffic(args.workload, world)[2] == bid,
+                # those bytes, read and written apart, priced at this box's own streaming rates (below): what is left between
+                # the model and the measured SpMV is the kernels', what is between the traffic and the algorithmic bytes the format's
+                "byte_cost_model": byte_cost_model(args.workload, world, stream, spmv_avg_ms),
                 # the same box's own streaming rates (read-only sum / copy over 1 GiB, rank 0) and the SpMV against them
                 "measured_stream_read_GBps": stream[0], "measured_stream_copy_GBps": stream[1],
                 "frac_of_measured_stream_read": achieved / (stream[0] * world) if stream[0] else None,

@@ -47,3 +47,23 @@ def test_traffic_kernels_exist_in_the_built_library():
         for kern in entry["kernels"]:
             base = re.search(r"(k_[a-z0-9_]+)", kern).group(1)
             assert base.encode() in blob, (key, kern)
+
+
+def test_byte_cost_model_prices_the_two_directions_apart():
+    """roofline.byte_cost_model: the measured bytes of one SpMV, read and written apart (their sum IS roofline.traffic), priced at the
+    box's own streaming rates; a copy (as many bytes each way) must cost exactly what the copy probe measured"""
+    b = _bench()
+    table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    read, copy = 6000.0, 5000.0
+    for key in ("c3", "c2", "er"):
+        m = b.byte_cost_model(key, 1, (read, copy), 1.0)
+        assert abs(m["read_bytes"] + m["written_bytes"] - table[key]["hbm_bytes_per_launch"]) < 1.0, key
+        assert m["read_bytes"] > m["written_bytes"] > 0
+        assert abs(m["ms"] - (m["read_bytes"] / read + m["written_bytes"] / m["write_GBps"]) * 1e-6) < 1e-12
+        assert abs(m["measured_over_model"] * m["ms"] - 1.0) < 1e-12
+    m = b.byte_cost_model("c3", 1, (read, copy), 1.0)
+    both = 1e9
+    assert abs((both / m["read_GBps"] + both / m["write_GBps"]) - 2 * both / copy) < 1e-6   # the copy probe's own time
+    assert b.byte_cost_model("c3", 8, (read, copy), 1.0) is None      # PMC passes exist for one GPU only
+    assert b.byte_cost_model("c1", 1, (read, copy), 1.0) is None      # no pass for this workload
+    assert b.byte_cost_model("c3", 1, (6000.0, 13000.0), 1.0) is None  # rates that imply a negative write cost: no model

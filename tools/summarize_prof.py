@@ -71,6 +71,11 @@ if len(sys.argv) > 3:
     table[sys.argv[3]] = {
         "build_id": ids.pop(),
         "kernels": kern, "hbm_bytes_per_launch": sum(kern.values()),
+        # the two directions apart (bench.py prices them separately: roofline.byte_cost_model)
+        "read_bytes_per_launch": sum(2.0 * d["FETCH_SIZE_KiB_avg_per_launch"] * 1024.0 for k, d in pmc.items()
+                                     if any(s in k for s in spmv) and "hbm_bytes_per_launch_corrected" in d),
+        "written_bytes_per_launch": sum(d["WRITE_SIZE_KiB_avg_per_launch"] * 1024.0 for k, d in pmc.items()
+                                        if any(s in k for s in spmv) and "hbm_bytes_per_launch_corrected" in d),
         "source": f"profiles/{tag}_pmc.json: sum over the kernels of one SpMV (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
                   "separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; the doubling was checked on k_scale / "
                   "k_axpy_norm, whose byte counts are known)"}
