@@ -15,6 +15,8 @@ Reference lines restated here (paths relative to /root/reference):
                     through scipy -- same symmetric-tridiagonal problem, the
                     result is invariant to eigenvector sign/order)
   * mult_out        serial/lib/multiplyOut.cc:17-37
+  * eigen_dstevd, mult_out_blas: the reference's own LAPACKE / CBLAS CALLS executed from SciPy's bundled OpenBLAS
+                    (eigen.cc:13; multiplyOut.cc:30,33) -- a pin for the two restatements above
 """
 from __future__ import annotations
 
@@ -235,6 +237,70 @@ def expm_action(row_offset, col_idx, k: int, x):
     alpha, beta, Q, xn = lanczos(row_offset, col_idx, k, x)
     lam, V = eigen(alpha, beta)
     return mult_out(Q, V, lam, xn)
+
+
+# --------------------------------------------------------------------------- the reference's own LIBRARY CALLS
+# serial/lib/eigen.cc:13 is one call, LAPACKE_dstevd(LAPACK_ROW_MAJOR, 'V', k, eigenvalues, beta, eigenvectors, k); serial/lib/
+# multiplyOut.cc:30,33 are two, cblas_dgemm (QV += Q V) and cblas_dgemv (ans += QV f).  lanczos.cc / eigen.cc / multiplyOut.cc cannot be
+# COMPILED here (no lapacke.h / cblas.h in the image, and no stand-ins are written), but the routines they call exist in the OpenBLAS that
+# SciPy bundles (exported with a scipy_ prefix): calling them with the reference's arguments executes the reference's post-loop
+# arithmetic itself -- a pin for eigen() and mult_out() above that does not go through this file's restatement of them.
+_BLAS = None
+
+
+def blas_calls():
+    """ctypes handle on SciPy's bundled OpenBLAS with the three routines the reference calls, or None where it is not found."""
+    global _BLAS
+    if _BLAS is None:
+        import glob
+        try:
+            import scipy
+            cands = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+            B = ctypes.CDLL(cands[0])
+            B.scipy_LAPACKE_dstevd.argtypes = [ctypes.c_int, ctypes.c_char, ctypes.c_int, _f64p, _f64p, _f64p, ctypes.c_int]
+            B.scipy_LAPACKE_dstevd.restype = ctypes.c_int
+            B.scipy_cblas_dgemm.argtypes = [ctypes.c_int] * 3 + [ctypes.c_int] * 3 + [ctypes.c_double, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                                                                      ctypes.c_double, _f64p, ctypes.c_int]
+            B.scipy_cblas_dgemm.restype = None
+            B.scipy_cblas_dgemv.argtypes = [ctypes.c_int] * 2 + [ctypes.c_int] * 2 + [ctypes.c_double, _f64p, ctypes.c_int, _f64p, ctypes.c_int,
+                                                                                      ctypes.c_double, _f64p, ctypes.c_int]
+            B.scipy_cblas_dgemv.restype = None
+            _BLAS = B
+        except (ImportError, IndexError, OSError, AttributeError):
+            _BLAS = False
+    return _BLAS or None
+
+
+def eigen_dstevd(alpha, beta):
+    """serial/lib/eigen.cc:13 executed: LAPACKE_dstevd(LAPACK_ROW_MAJOR = 101, 'V', k, d, e, z, k).  Returns (lam, V) as eigen() does."""
+    B = blas_calls()
+    assert B is not None, "SciPy's OpenBLAS not found"
+    k = len(alpha)
+    d = np.array(alpha, dtype=np.float64)
+    e = np.zeros(max(k, 1))
+    e[:k - 1] = np.asarray(beta, dtype=np.float64)[:k - 1]
+    z = np.zeros((k, k))
+    info = B.scipy_LAPACKE_dstevd(101, b"V", k, _p(d, _f64p), _p(e, _f64p), _p(z, _f64p), k)
+    assert info == 0, info
+    return d, z
+
+
+def mult_out_blas(Q_rowmajor, V, lam, x_norm):
+    """serial/lib/multiplyOut.cc:21-33 executed: exp, the elementwise product with ||x|| * (first row of the eigenvectors), then the
+    reference's cblas_dgemm(RowMajor = 101, NoTrans = 111, NoTrans, n, k, k, 1, Q, k, V, k, 1, QV, k) and cblas_dgemv(RowMajor, NoTrans,
+    n, k, 1, QV, k, f, 1, 1, ans, 1) -- QV and ans start as zeros (the reference accumulates with beta = 1 into fresh pages)."""
+    B = blas_calls()
+    assert B is not None, "SciPy's OpenBLAS not found"
+    Q = np.ascontiguousarray(Q_rowmajor, dtype=np.float64)
+    Vc = np.ascontiguousarray(V, dtype=np.float64)
+    n, k = Q.shape
+    f = np.exp(np.asarray(lam, dtype=np.float64))
+    f = np.ascontiguousarray(f * (x_norm * Vc[0, :]))
+    QV = np.zeros((n, k))
+    ans = np.zeros(n)
+    B.scipy_cblas_dgemm(101, 111, 111, n, k, k, 1.0, _p(Q, _f64p), k, _p(Vc, _f64p), k, 1.0, _p(QV, _f64p), k)
+    B.scipy_cblas_dgemv(101, 111, n, k, 1.0, _p(QV, _f64p), k, _p(f, _f64p), 1, 1.0, _p(ans, _f64p), 1)
+    return ans
 
 
 # --------------------------------------------------------------------------- real reference

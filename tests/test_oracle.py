@@ -168,3 +168,37 @@ def test_all_core_companion_agrees_with_the_single_thread_loop():
     assert threads == 4 and xn2 == xn
     assert abs(a2[0] - a[0]) <= 1e-12 * abs(a[0]) and abs(b2[0] - b[0]) <= 1e-12 * abs(b[0])
     assert np.allclose(a2[:4], a[:4], rtol=1e-9, atol=1e-9 * np.abs(a).max()) and np.allclose(b2[:3], b[:3], rtol=1e-9)
+
+
+def test_post_loop_steps_equal_the_reference_library_calls(oracle):
+    """serial/lib/eigen.cc:13 and multiplyOut.cc:30,33 are three library calls -- LAPACKE_dstevd, cblas_dgemm, cblas_dgemv.  Their
+    sources cannot be compiled here (no lapacke.h / cblas.h), but the routines themselves are in SciPy's bundled OpenBLAS: executed
+    with the reference's arguments (oracle.eigen_dstevd / mult_out_blas) they reproduce the fixtures' `ans` from the fixtures' own
+    alpha / beta, and the oracle's restatements of the two steps agree with them -- at the fixtures' k and at BASELINE's k = 50,
+    where dstevd takes its divide-and-conquer path (k > 25) and dstev, which oracle.eigen calls, does not."""
+    import glob
+    O = oracle
+    if O.blas_calls() is None:
+        pytest.skip("SciPy's bundled OpenBLAS not found")
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))):
+        g = np.load(path)
+        n, k = int(g["mtx_n"]), int(g["k"])
+        ro, ci = g["ref_row_offset"].astype(np.uint64), g["ref_col_idx"].astype(np.uint32)
+        alpha, beta, Q, xn = O.lanczos(ro, ci, k, np.ones(n))
+        assert np.array_equal(alpha, g["alpha"]) and np.array_equal(beta, g["beta"])
+        lam, V = O.eigen_dstevd(g["alpha"], g["beta"])           # the reference's eigen step on the fixture's coefficients
+        ans = O.mult_out_blas(Q, V, lam, xn)                     # ... and its multOut
+        assert np.abs(ans - g["ans"]).max() <= 1e-13 * np.abs(g["ans"]).max(), path
+        lam_o, V_o = O.eigen(alpha, beta)
+        assert np.abs(lam - lam_o).max() <= 1e-13 * np.abs(lam).max(), path
+        assert np.abs(O.mult_out(Q, V_o, lam_o, xn) - ans).max() <= 1e-13 * np.abs(ans).max(), path
+    # BASELINE's k: a 1 M-entry graph at k = 50; the answer through e^(A - theta_max) so that fp64 holds it
+    ro, ci = O.gen_rmat(14, 12000, 120000, 1234)
+    n = len(ro) - 1
+    alpha, beta, Q, xn = O.lanczos(ro, ci, 50, np.ones(n))
+    lam, V = O.eigen_dstevd(alpha, beta)
+    lam_o, V_o = O.eigen(alpha, beta)
+    assert np.abs(lam - lam_o).max() <= 1e-13 * np.abs(lam).max()
+    shift = lam.max()
+    a1, a2 = O.mult_out_blas(Q, V, lam - shift, xn), O.mult_out(Q, V_o, lam_o - shift, xn)
+    assert np.abs(a1 - a2).max() <= 1e-12 * np.abs(a1).max()
